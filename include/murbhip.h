@@ -1,0 +1,153 @@
+/*
+ * murbhip.h — C ABI of the MI355X-native all-pairs force + integrate path for MUrB.
+ *
+ * This is the drop-in boundary: everything the reference's `--im` implementations do on the
+ * device side of SimulationNBodyInterface<T>::computeOneIteration()
+ * (reference src/common/core/SimulationNBodyInterface.hpp:45) is reachable through these
+ * entry points with plain pointers and sizes.  The only translation unit behind it that needs
+ * hipcc is nbody-eurohpc_amd/csrc/murbhip.hip; host code (C++, or ctypes/cgo/JNI) links
+ * libmurbhip.so and never sees a HIP header.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative value on failure:
+ *       -1 … -999     : -(hipError_t)
+ *       -1000 … -1999 : -(1000 + ncclResult_t)
+ *       -2000 …       : MURBHIP_E_* argument / state errors
+ *     murbhip_error_string() turns any of them into text.  The C++ wrapper maps non-zero to the
+ *     reference's print-to-stderr + exit(code) convention
+ *     (reference src/murb/implem/SimulationNBodyCUDATileFullDevice.cu:10-17).
+ *   - a context is driven by ONE host thread (reference driver contract, src/murb/main.cpp:348-354).
+ *   - step functions only enqueue work; murbhip_sync() is the per-iteration device sync the
+ *     reference driver performs itself (src/murb/main.cpp:356-368).
+ *   - arrays are fp32 SoA of n entries in the reference's body order (dataSoA_t,
+ *     src/common/core/Bodies.hpp:15-24).  SIMD padding bodies (Bodies.cpp:201-213) are NOT passed
+ *     in: they carry no mass and no implementation of the reference reads them in the j loop.
+ */
+#ifndef MURBHIP_H_
+#define MURBHIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct murbhip_ctx murbhip_ctx;
+
+#define MURBHIP_UNIQUE_ID_BYTES 128
+
+#define MURBHIP_E_INVALID (-2000)   /* bad argument                                   */
+#define MURBHIP_E_STATE (-2001)     /* call made in the wrong state (e.g. no upload)  */
+#define MURBHIP_E_NO_DEVICE (-2002) /* no usable HIP device                           */
+#define MURBHIP_E_NO_RCCL (-2003)   /* librccl could not be loaded                    */
+#define MURBHIP_E_NOMEM (-2004)     /* host allocation failed                         */
+
+/* ------------------------------------------------------------------ host-only helpers (no GPU needed) */
+
+/* ABI version of this header (major*100 + minor). */
+int murbhip_version(void);
+
+/* Text for any return code of this library (static storage, never NULL). */
+const char* murbhip_error_string(int code);
+
+/* Block partition of n bodies over `world` ranks: first index and count of rank `rank`.
+ * Same rule as the reference's MPI path: counts[r] = n/world + (r < n%world), displs = prefix sums
+ * (reference src/murb/implem/SimulationNBodyMultiNode.cpp:76-91). */
+int murbhip_partition(unsigned long n, int world, int rank, unsigned long* first, unsigned long* count);
+
+/* Device slots each rank owns in the replicated position buffer: the largest slice rounded up to
+ * the layout tile (a multiple of 512 bodies).  Slots past a rank's count hold mass 0 and contribute
+ * exactly 0 to every sum, so one equal-count all-gather replaces the reference's MPI_Allgatherv
+ * (SimulationNBodyMultiNode.cpp:104-114). */
+unsigned long murbhip_slice_slots(unsigned long n, int world);
+
+/* Slot of body i in the replicated buffer (rank(i) * slice_slots + offset inside its slice). */
+unsigned long murbhip_slot_of_body(unsigned long n, int world, unsigned long i);
+
+/* ------------------------------------------------------------------ life cycle */
+
+/* Number of visible HIP devices. */
+int murbhip_device_count(int* count);
+
+/* One GPU, whole problem.  Replaces what the reference does at construction of a device
+ * implementation: CUDABodies allocation (src/common/core/CUDABodies.cu:12-31), acceleration and
+ * GM buffers (SimulationNBodyCUDATileFullDevice.cu:181-199).  `g` is the gravitational constant
+ * (SimulationNBodyInterface.hpp:18), `soft` the softening length (squared inside). */
+int murbhip_create(murbhip_ctx** out, unsigned long n, float soft, float g, int device);
+
+/* One process driving `ndev` GPUs (bodies block-partitioned over them, positions exchanged every
+ * step).  `devices` lists HIP device ordinals; the same ordinal may appear more than once (the
+ * shards then share that GPU — used to exercise the sharded path on a one-GPU machine).
+ * exchange: 0 = device-to-device copies issued by this library, 1 = RCCL all-gather. */
+int murbhip_create_sharded(murbhip_ctx** out, unsigned long n, float soft, float g, int ndev, const int* devices,
+                           int exchange);
+
+/* One process per GPU (torchrun / mpirun style).  Rank 0 calls murbhip_unique_id() and ships the
+ * 128 bytes to every rank out of band; every rank then calls murbhip_create_rank().  Takes the place
+ * of the reference's lazy MPI_Init/Comm_rank/Comm_size (SimulationNBodyMultiNode.cpp:62-73). */
+int murbhip_unique_id(void* id_out /* MURBHIP_UNIQUE_ID_BYTES */);
+int murbhip_create_rank(murbhip_ctx** out, unsigned long n, float soft, float g, int device, int rank, int world,
+                        const void* unique_id);
+
+int murbhip_destroy(murbhip_ctx* ctx);
+
+/* ------------------------------------------------------------------ state in / out */
+
+/* Host SoA -> device (all n bodies; every rank passes the full arrays, as every reference MPI rank
+ * builds the full Bodies).  Replaces CUDABodies::memcpyBuffersOnDevice (CUDABodies.cu:34-49) and
+ * devInitializeDevGM (SimulationNBodyCUDATileFullDevice.cu:41-45): G*m is folded in here. */
+int murbhip_upload(murbhip_ctx* ctx, const float* qx, const float* qy, const float* qz, const float* vx,
+                   const float* vy, const float* vz, const float* m);
+
+/* Device -> host SoA of all n bodies; waits for enqueued steps first.  This is the lazy D2H behind
+ * CUDABodies::getDataSoA() (CUDABodies.cu:64-93).  Any pointer may be NULL.  In rank mode velocities
+ * are only known for the caller's own slice: entries of other ranks are left untouched. */
+int murbhip_download_state(murbhip_ctx* ctx, float* qx, float* qy, float* qz, float* vx, float* vy, float* vz);
+
+/* Accelerations used by the most recent step (or murbhip_compute_acc), n entries each; other ranks'
+ * entries untouched in rank mode.  Test hook, like getAccSoA()
+ * (SimulationNBodyCUDATileFullDevice200k.cu:179-189). */
+int murbhip_download_acc(murbhip_ctx* ctx, float* ax, float* ay, float* az);
+
+/* ------------------------------------------------------------------ compute */
+
+/* a_i = sum_j G m_j (q_j - q_i) / (|q_j - q_i|^2 + soft^2)^(3/2) for the current positions, no
+ * integration.  Enqueue only.  (computeBodiesAcceleration: SimulationNBodyOptim.cpp:34-94,
+ * device twin SimulationNBodyCUDATileFullDevice.cu:53-153.) */
+int murbhip_compute_acc(murbhip_ctx* ctx);
+
+/* One iteration = force + position/velocity update [+ position exchange].  Enqueue only.
+ * (computeOneIteration: SimulationNBodyCUDATileFullDevice.cu:203-236; integrator semantics
+ * Bodies.cpp:260-278 / CUDABodies.cu:126-153, including the fp64 intermediates.) */
+int murbhip_step(murbhip_ctx* ctx, float dt);
+
+/* `iterations` calls of murbhip_step in one go. */
+int murbhip_steps(murbhip_ctx* ctx, float dt, int iterations);
+
+/* Integrator alone with caller-supplied accelerations (host SoA, n entries): the overload
+ * CUDABodies::updatePositionsAndVelocities(const accSoA_t&, T&) (CUDABodies.cu:355-370) that the
+ * reference's test_CUDABodies.cpp:42-75 drives. */
+int murbhip_integrate_host_acc(murbhip_ctx* ctx, const float* ax, const float* ay, const float* az, float dt);
+
+/* Wait for everything enqueued on this context; returns the first asynchronous error, if any. */
+int murbhip_sync(murbhip_ctx* ctx);
+
+/* ------------------------------------------------------------------ tuning and measurement */
+
+/* Integer options.  Keys:
+ *   "variant"        force kernel variant (0 = library default)
+ *   "jsplit"         number of j-chunks a body's sum is split into (0 = auto)
+ *   "profile"        1: bracket every force kernel with HIP events (read with murbhip_get_info)
+ *   "overlap"        sharded/rank mode: 1 (default) own-slice tiles first, exchange on the 2nd stream
+ */
+int murbhip_set_option(murbhip_ctx* ctx, const char* key, long value);
+
+/* Numeric facts.  Keys: "cu_count", "clock_mhz", "n", "slots", "world", "rank", "jsplit", "variant",
+ * "force_launches", "force_ms_avg", "force_ms_total", "interactions_per_launch",
+ * "device_bytes". */
+int murbhip_get_info(murbhip_ctx* ctx, const char* key, double* value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MURBHIP_H_ */

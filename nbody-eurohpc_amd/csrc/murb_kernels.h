@@ -1,0 +1,284 @@
+// gfx950 (CDNA4) kernels of the all-pairs force + integrate path.  Device code only; included by
+// murbhip.hip (the C-ABI translation unit) and by tools/kernel_lab.hip (A/B timing of variants).
+//
+// What is computed (reference SimulationNBodyOptim.cpp:34-94; device twin
+// SimulationNBodyCUDATileFullDevice.cu:110-137):
+//     a_i = sum_j  GM_j * (q_j - q_i) * (|q_j - q_i|^2 + soft^2)^(-3/2)
+// in fp32, full N^2 form (the j == i term is exactly 0 because q_j - q_i = 0 and soft > 0).
+//
+// How it is mapped to the machine (this is NOT the reference's one-thread-per-body tiling):
+//   * the i bodies of a wavefront are wave-uniform: R of them live in SGPRs, so every VALU
+//     instruction reads its i operand from the scalar file for free;
+//   * the j bodies are spread over the 64 lanes, two per lane, in the pair layout of murb_layout.h,
+//     so the twelve arithmetic instructions of an interaction issue as packed fp32
+//     (v_pk_add/v_pk_mul/v_pk_fma_f32) on two interactions at once; only v_rsq_f32 is per element;
+//   * j tiles are staged global -> LDS once per workgroup and read back with conflict-free
+//     ds_read_b128, one 16-byte read feeding R*2 interactions per lane;
+//   * a body's sum is therefore spread over 64 lanes x 2 halves [x jsplit chunks]; it is folded
+//     with a wavefront-wide DPP/shuffle reduction at the end of the j sweep and the per-chunk
+//     partial sums are added in fixed order by the integrate kernel (bit-reproducible).
+// The work per wavefront is R x (chunk length) interactions, so N = 30 000 already yields thousands
+// of wavefronts for 256 CUs x 4 SIMDs (the reference's 1024-bodies-per-block tiling gives 30 blocks).
+#ifndef MURB_KERNELS_H_
+#define MURB_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include "murb_layout.h"
+
+typedef float murb_f2 __attribute__((ext_vector_type(2)));
+
+// Which tiles of the record buffer a launch sweeps as j: `count` virtual tiles starting at
+// `offset`, with a hole of `skip_len` tiles at virtual index `skip_at` (sharded mode sweeps "own
+// slice" and "everything but own slice" in two launches so the exchange can overlap the first).
+struct MurbTileRange {
+    int offset, count, skip_at, skip_len;
+};
+
+struct MurbForceArgs {
+    const float4* rec;   // body records, all slots (murb_layout.h)
+    float4* accp;        // partial sums: accp[chunk * acc_stride + local_slot] = {ax, ay, az, 0}
+    MurbTileRange tiles; // j range of this launch
+    int i_first_slot;    // first slot of the i slice (tile aligned)
+    int chunk_first;     // partial-sum row of this launch's chunk 0
+    int nchunks;         // gridDim.y
+    unsigned int acc_stride;   // slots per partial-sum row
+    float soft2;
+};
+
+__device__ __forceinline__ int murb_actual_tile(const MurbTileRange& tr, int v)
+{
+    return tr.offset + v + (v >= tr.skip_at ? tr.skip_len : 0);
+}
+
+// ---- wavefront-wide sum: every lane ends up with the total ------------------------------------
+// Rows of 16 lanes are folded with DPP (no LDS traffic), the four row totals are combined through
+// v_readlane: 4 DPP adds + 4 readlanes + 3 adds per value.
+__device__ __forceinline__ float murb_wave_sum(float v)
+{
+    // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// ---- one i body against two j bodies (packed) ---------------------------------------------------
+// 3 pk_add + 3 pk_fma + 2 rsq + 3 pk_mul + 3 pk_fma: the instruction mix DESIGN.md's roofline counts.
+__device__ __forceinline__ void murb_interact_pk(const murb_f2 xj, const murb_f2 yj, const murb_f2 zj,
+                                                 const murb_f2 gj, const float xi, const float yi, const float zi,
+                                                 const float soft2, murb_f2& ax, murb_f2& ay, murb_f2& az)
+{
+    const murb_f2 dx = xj - xi;
+    const murb_f2 dy = yj - yi;
+    const murb_f2 dz = zj - zi;
+    murb_f2 r2 = __builtin_elementwise_fma(dx, dx, (murb_f2)(soft2));
+    r2 = __builtin_elementwise_fma(dy, dy, r2);
+    r2 = __builtin_elementwise_fma(dz, dz, r2);
+    murb_f2 inv;
+    inv.x = __builtin_amdgcn_rsqf(r2.x);
+    inv.y = __builtin_amdgcn_rsqf(r2.y);
+    const murb_f2 inv2 = inv * inv;
+    const murb_f2 gi = gj * inv;
+    const murb_f2 s = gi * inv2;   // GM_j * inv^3, never G*inv^3 alone (fp32 range)
+    ax = __builtin_elementwise_fma(s, dx, ax);
+    ay = __builtin_elementwise_fma(s, dy, ay);
+    az = __builtin_elementwise_fma(s, dz, az);
+}
+
+// Same arithmetic, one j at a time (A/B reference for the packed form).
+__device__ __forceinline__ void murb_interact_sc(const float xj, const float yj, const float zj, const float gj,
+                                                 const float xi, const float yi, const float zi, const float soft2,
+                                                 float& ax, float& ay, float& az)
+{
+    const float dx = xj - xi, dy = yj - yi, dz = zj - zi;
+    float r2 = __builtin_fmaf(dx, dx, soft2);
+    r2 = __builtin_fmaf(dy, dy, r2);
+    r2 = __builtin_fmaf(dz, dz, r2);
+    const float inv = __builtin_amdgcn_rsqf(r2);
+    const float s = (gj * inv) * (inv * inv);
+    ax = __builtin_fmaf(s, dx, ax);
+    ay = __builtin_fmaf(s, dy, ay);
+    az = __builtin_fmaf(s, dz, az);
+}
+
+// Variant tags (template parameter MODE)
+#define MURB_MODE_PK_LDS 1      // packed math, j tiles staged in LDS            (default)
+#define MURB_MODE_PK_DIRECT 2   // packed math, j read straight from L2/HBM per wave
+#define MURB_MODE_SC_LDS 3      // scalar math, j tiles staged in LDS
+
+// ---- force kernel --------------------------------------------------------------------------------
+// grid.x = i groups of WAVES*R bodies, grid.y = j chunks.  LDS: STAGE layout tiles (8 KiB each).
+template <int MODE, int R, int WAVES, int STAGE>
+__global__ __launch_bounds__(WAVES * 64) void murb_force_kernel(const MurbForceArgs a)
+{
+    static_assert(R % 2 == 0 && MURB_TILE_BODIES % (WAVES * R) == 0, "i groups must tile the layout");
+    __shared__ float4 lds[(MODE == MURB_MODE_PK_DIRECT) ? 1 : STAGE * MURB_TILE_F4];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i_slot = a.i_first_slot + (blockIdx.x * WAVES + wave) * R;   // wave-uniform
+
+    // the wave's R i bodies -> scalar registers
+    float xi[R], yi[R], zi[R];
+    {
+        const unsigned long ra = murb_rec_a((unsigned long)(i_slot >> 1));
+#pragma unroll
+        for (int h = 0; h < R / 2; ++h) {
+            const float4 A = a.rec[ra + h];
+            const float4 B = a.rec[ra + h + MURB_TILE_PAIRS];
+            xi[2 * h] = A.x; xi[2 * h + 1] = A.y;
+            yi[2 * h] = A.z; yi[2 * h + 1] = A.w;
+            zi[2 * h] = B.x; zi[2 * h + 1] = B.y;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            xi[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xi[r])));
+            yi[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, yi[r])));
+            zi[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, zi[r])));
+        }
+    }
+
+    // this block's j chunk: virtual tiles [vt0, vt1)
+    const int chunk = blockIdx.y;
+    const int vt0 = (int)(((long)a.tiles.count * chunk) / a.nchunks);
+    const int vt1 = (int)(((long)a.tiles.count * (chunk + 1)) / a.nchunks);
+    const float soft2 = a.soft2;
+
+    murb_f2 ax[R], ay[R], az[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { ax[r] = (murb_f2)(0.f); ay[r] = (murb_f2)(0.f); az[r] = (murb_f2)(0.f); }
+
+    if (MODE == MURB_MODE_PK_DIRECT) {
+        for (int vt = vt0; vt < vt1; ++vt) {
+            const float4* tile = a.rec + (unsigned long)murb_actual_tile(a.tiles, vt) * MURB_TILE_F4;
+#pragma unroll
+            for (int q = 0; q < MURB_TILE_PAIRS; q += 64) {
+                const float4 A = tile[q + lane];
+                const float4 B = tile[q + lane + MURB_TILE_PAIRS];
+                const murb_f2 xj = {A.x, A.y}, yj = {A.z, A.w}, zj = {B.x, B.y}, gj = {B.z, B.w};
+#pragma unroll
+                for (int r = 0; r < R; ++r) murb_interact_pk(xj, yj, zj, gj, xi[r], yi[r], zi[r], soft2, ax[r], ay[r], az[r]);
+            }
+        }
+    } else {
+        for (int vs = vt0; vs < vt1; vs += STAGE) {
+            const int nt = (vt1 - vs) < STAGE ? (vt1 - vs) : STAGE;
+            __syncthreads();   // previous stage fully consumed
+            for (int t = 0; t < nt; ++t) {
+                const float4* src = a.rec + (unsigned long)murb_actual_tile(a.tiles, vs + t) * MURB_TILE_F4;
+#pragma unroll
+                for (int k = threadIdx.x; k < MURB_TILE_F4; k += WAVES * 64) lds[t * MURB_TILE_F4 + k] = src[k];
+            }
+            __syncthreads();
+            for (int t = 0; t < nt; ++t) {
+                const float4* tile = lds + t * MURB_TILE_F4;
+#pragma unroll
+                for (int q = 0; q < MURB_TILE_PAIRS; q += 64) {
+                    const float4 A = tile[q + lane];
+                    const float4 B = tile[q + lane + MURB_TILE_PAIRS];
+                    if (MODE == MURB_MODE_PK_LDS) {
+                        const murb_f2 xj = {A.x, A.y}, yj = {A.z, A.w}, zj = {B.x, B.y}, gj = {B.z, B.w};
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            murb_interact_pk(xj, yj, zj, gj, xi[r], yi[r], zi[r], soft2, ax[r], ay[r], az[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            float tx = ax[r].x, ty = ay[r].x, tz = az[r].x;
+                            float ux = ax[r].y, uy = ay[r].y, uz = az[r].y;
+                            murb_interact_sc(A.x, A.z, B.x, B.z, xi[r], yi[r], zi[r], soft2, tx, ty, tz);
+                            murb_interact_sc(A.y, A.w, B.y, B.w, xi[r], yi[r], zi[r], soft2, ux, uy, uz);
+                            ax[r] = (murb_f2){tx, ux}; ay[r] = (murb_f2){ty, uy}; az[r] = (murb_f2){tz, uz};
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // fold the 64 lanes x 2 halves of every accumulator; lane r keeps body r's total
+    float ox = 0.f, oy = 0.f, oz = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float sx = murb_wave_sum(ax[r].x + ax[r].y);
+        const float sy = murb_wave_sum(ay[r].x + ay[r].y);
+        const float sz = murb_wave_sum(az[r].x + az[r].y);
+        if (lane == r) { ox = sx; oy = sy; oz = sz; }
+    }
+    if (lane < R) {
+        const unsigned long row = (unsigned long)(a.chunk_first + chunk) * a.acc_stride;
+        a.accp[row + (unsigned long)(i_slot - a.i_first_slot) + lane] = make_float4(ox, oy, oz, 0.f);
+    }
+}
+
+// ---- integrate ------------------------------------------------------------------------------------
+// Reference semantics, Bodies.cpp:260-278 (= CUDABodies.cu:126-153):
+//     aDt = a*dt (fp32);  q' = q + (v + aDt*0.5)*dt with the parenthesis and the add evaluated in
+//     fp64 (the literal 0.5 is a double) and rounded once to fp32;  v' = v + aDt (fp32).
+// The _rn intrinsics keep hipcc from contracting these into FMAs, which would change the rounding.
+struct MurbIntegrateArgs {
+    const float4* rec_in;    // all slots
+    float4* rec_out;         // all slots (other buffer); only the local slice is written
+    float4* vel;             // local slice, pair layout
+    const float4* accp;      // partial sums [nparts][acc_stride]
+    float* acc_out;          // ax | ay | az, acc_stride entries each (sum of the partials)
+    int i_first_slot;        // first slot of the local slice
+    int count;               // real bodies in the local slice
+    int nparts;
+    unsigned int acc_stride;
+    float dt;
+    int update_state;        // 0: only reduce partial sums into acc_out
+};
+
+__device__ __forceinline__ float murb_drift(float q, float v, float a_dt, float dt)
+{
+    const double half_kick = __dmul_rn((double)a_dt, 0.5);
+    const double vel_mid = __dadd_rn((double)v, half_kick);
+    return (float)__dadd_rn((double)q, __dmul_rn(vel_mid, (double)dt));
+}
+
+__global__ __launch_bounds__(256) void murb_integrate_kernel(const MurbIntegrateArgs a)
+{
+    const int lp = blockIdx.x * blockDim.x + threadIdx.x;   // local pair
+    const int s0 = 2 * lp;                                    // local slots s0, s0+1
+    if (s0 >= (int)a.acc_stride) return;
+
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+    for (int p = 0; p < a.nparts; ++p) {
+        const float4 u = a.accp[(unsigned long)p * a.acc_stride + s0];
+        const float4 w = a.accp[(unsigned long)p * a.acc_stride + s0 + 1];
+        acc0.x += u.x; acc0.y += u.y; acc0.z += u.z;
+        acc1.x += w.x; acc1.y += w.y; acc1.z += w.z;
+    }
+    a.acc_out[s0] = acc0.x; a.acc_out[s0 + 1] = acc1.x;
+    a.acc_out[a.acc_stride + s0] = acc0.y; a.acc_out[a.acc_stride + s0 + 1] = acc1.y;
+    a.acc_out[2u * a.acc_stride + s0] = acc0.z; a.acc_out[2u * a.acc_stride + s0 + 1] = acc1.z;
+    if (!a.update_state) return;
+
+    const unsigned long gp = (unsigned long)(a.i_first_slot >> 1) + lp;   // global pair
+    const unsigned long ra = murb_rec_a(gp);
+    const unsigned long va = murb_rec_a((unsigned long)lp);
+    float4 A = a.rec_in[ra], B = a.rec_in[ra + MURB_TILE_PAIRS];
+    float4 VA = a.vel[va], VB = a.vel[va + MURB_TILE_PAIRS];
+    const float dt = a.dt;
+    if (s0 < a.count) {
+        const float kx = __fmul_rn(acc0.x, dt), ky = __fmul_rn(acc0.y, dt), kz = __fmul_rn(acc0.z, dt);
+        A.x = murb_drift(A.x, VA.x, kx, dt); A.z = murb_drift(A.z, VA.z, ky, dt); B.x = murb_drift(B.x, VB.x, kz, dt);
+        VA.x = __fadd_rn(VA.x, kx); VA.z = __fadd_rn(VA.z, ky); VB.x = __fadd_rn(VB.x, kz);
+    }
+    if (s0 + 1 < a.count) {
+        const float kx = __fmul_rn(acc1.x, dt), ky = __fmul_rn(acc1.y, dt), kz = __fmul_rn(acc1.z, dt);
+        A.y = murb_drift(A.y, VA.y, kx, dt); A.w = murb_drift(A.w, VA.w, ky, dt); B.y = murb_drift(B.y, VB.y, kz, dt);
+        VA.y = __fadd_rn(VA.y, kx); VA.w = __fadd_rn(VA.w, ky); VB.y = __fadd_rn(VB.y, kz);
+    }
+    a.rec_out[ra] = A; a.rec_out[ra + MURB_TILE_PAIRS] = B;
+    a.vel[va] = VA; a.vel[va + MURB_TILE_PAIRS] = VB;
+}
+
+#endif

@@ -1,0 +1,779 @@
+// libmurbhip.so — the C ABI of include/murbhip.h: context, residency, launches, exchange.
+// The only translation unit of the product that needs hipcc.
+//
+// Design notes (full text in DESIGN.md):
+//   * body state stays resident in HBM for the whole simulation (reference twin:
+//     CUDABodies, src/common/core/CUDABodies.cu:12-49); the only per-iteration host work is
+//     enqueueing 2-3 kernels;
+//   * positions are double-buffered: a step reads rec[cur] and the integrate kernel writes
+//     rec[cur^1], so no kernel ever reads a buffer another kernel (or a peer GPU) is writing;
+//   * multi-GPU: bodies are block-partitioned (murbhip_partition) into equal tile-aligned slot
+//     ranges of one replicated record buffer; after its integrate a shard publishes its slice with
+//     ONE in-place all-gather (RCCL, loaded lazily with dlopen) or with peer copies, on a second
+//     stream, while the compute stream already sweeps the j tiles of its own slice.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/murbhip.h"
+#include "murb_kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------ error codes
+inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
+inline int nccl_rc(int r) { return r == 0 ? 0 : -(1000 + r); }
+
+#define HIP_TRY(expr)                        \
+    do {                                     \
+        const int rc_ = hip_rc((expr));      \
+        if (rc_ != 0) return rc_;            \
+    } while (0)
+#define RC_TRY(expr)                \
+    do {                            \
+        const int rc_ = (expr);     \
+        if (rc_ != 0) return rc_;   \
+    } while (0)
+
+// ------------------------------------------------------------------------------------ lazy RCCL
+// Only the sharded/rank modes need RCCL, and a Python host may already have loaded its own build of
+// it: bind at run time by soname instead of linking.
+typedef struct { char internal[MURBHIP_UNIQUE_ID_BYTES]; } rccl_id_t;
+typedef void* rccl_comm_t;
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(rccl_id_t*) = nullptr;
+    int (*CommInitRank)(rccl_comm_t*, int, rccl_id_t, int) = nullptr;
+    int (*CommInitAll)(rccl_comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(rccl_comm_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+constexpr int kRcclFloat = 7;   // ncclFloat32
+
+Rccl& rccl()
+{
+    static Rccl r;
+    if (r.lib || r.ok) return r;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) {
+        r.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return r;
+    r.GetUniqueId = (int (*)(rccl_id_t*))dlsym(r.lib, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(rccl_comm_t*, int, rccl_id_t, int))dlsym(r.lib, "ncclCommInitRank");
+    r.CommInitAll = (int (*)(rccl_comm_t*, int, const int*))dlsym(r.lib, "ncclCommInitAll");
+    r.CommDestroy = (int (*)(rccl_comm_t))dlsym(r.lib, "ncclCommDestroy");
+    r.AllGather = (int (*)(const void*, void*, size_t, int, rccl_comm_t, hipStream_t))dlsym(r.lib, "ncclAllGather");
+    r.GroupStart = (int (*)())dlsym(r.lib, "ncclGroupStart");
+    r.GroupEnd = (int (*)())dlsym(r.lib, "ncclGroupEnd");
+    r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllGather && r.GroupStart &&
+           r.GroupEnd;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------ partition (host only)
+void partition(unsigned long n, int world, int rank, unsigned long* first, unsigned long* count)
+{
+    const unsigned long base = n / (unsigned long)world, rem = n % (unsigned long)world;
+    const unsigned long r = (unsigned long)rank;
+    *count = base + (r < rem ? 1 : 0);
+    *first = r * base + std::min(r, rem);
+}
+
+unsigned long slice_slots(unsigned long n, int world)
+{
+    unsigned long first, count;
+    partition(n, world, 0, &first, &count);   // rank 0 always holds the largest slice
+    return murb_round_up_tile(std::max(count, 1ul));
+}
+
+// ------------------------------------------------------------------------------------ context
+struct Shard {
+    int device = 0;
+    int rank = 0;
+    unsigned long first = 0, count = 0;   // global body range owned
+    hipStream_t compute = nullptr, comm = nullptr;
+    hipEvent_t ev_integrated = nullptr, ev_gathered = nullptr;
+    float4* rec[2] = {nullptr, nullptr};
+    float4* vel = nullptr;
+    float4* accp = nullptr;
+    float* acc_out = nullptr;
+    rccl_comm_t comm_rccl = nullptr;
+    std::vector<hipEvent_t> prof;   // start/stop pairs around force launches
+    size_t prof_used = 0;
+    size_t bytes = 0;
+};
+
+constexpr int kMaxParts = 64;          // rows of the partial-sum buffer
+constexpr size_t kProfPairs = 2048;
+
+}  // namespace
+
+struct murbhip_ctx {
+    unsigned long n = 0;
+    int world = 1;
+    unsigned long slice = 0;   // slots per rank
+    unsigned long slots = 0;   // world * slice
+    float soft2 = 0.f, g = 0.f;
+    int exchange = 0;          // 0 peer copies, 1 RCCL
+    bool rank_mode = false;    // one shard here, the others live in other processes
+    std::vector<Shard> shards;
+    int cur = 0;               // record buffer holding the current positions
+    bool uploaded = false;
+    bool gather_pending = false;   // an exchange into rec[cur] is in flight on the comm streams
+    // options
+    int variant = 0, jsplit = 0, profile = 0, overlap = 1;
+    // facts
+    int cu_count = 0, clock_mhz = 0;
+    int last_parts = 0;
+    double interactions_per_launch = 0;
+    int async_error = 0;
+};
+
+namespace {
+
+struct Plan {
+    int variant;   // resolved
+    int R, waves;
+    int parts_local, parts_remote;   // j chunks for the own-slice launch and the rest
+};
+
+template <int MODE, int R, int WAVES, int STAGE>
+int launch_force_t(const MurbForceArgs& a, int i_slots, hipStream_t s)
+{
+    const dim3 grid((unsigned)((i_slots + WAVES * R - 1) / (WAVES * R)), (unsigned)a.nchunks, 1);
+    hipLaunchKernelGGL((murb_force_kernel<MODE, R, WAVES, STAGE>), grid, dim3(WAVES * 64), 0, s, a);
+    return hip_rc(hipGetLastError());
+}
+
+// variant table: id -> (mode, R).  Keep in sync with DESIGN.md and tools/kernel_lab.hip.
+int launch_force(int variant, const MurbForceArgs& a, int i_slots, hipStream_t s)
+{
+    switch (variant) {
+        case 1: return launch_force_t<MURB_MODE_PK_LDS, 8, 4, 4>(a, i_slots, s);
+        case 2: return launch_force_t<MURB_MODE_PK_LDS, 4, 4, 4>(a, i_slots, s);
+        case 3: return launch_force_t<MURB_MODE_PK_DIRECT, 8, 4, 1>(a, i_slots, s);
+        case 4: return launch_force_t<MURB_MODE_SC_LDS, 8, 4, 4>(a, i_slots, s);
+        case 5: return launch_force_t<MURB_MODE_PK_LDS, 16, 4, 4>(a, i_slots, s);
+        case 6: return launch_force_t<MURB_MODE_PK_DIRECT, 4, 4, 1>(a, i_slots, s);
+        default: return MURBHIP_E_INVALID;
+    }
+}
+constexpr int kNumVariants = 6;
+constexpr int kDefaultVariant = 1;
+
+int variant_group(int variant)   // bodies per workgroup = waves * R
+{
+    switch (variant) {
+        case 2: case 6: return 16;
+        case 5: return 64;
+        default: return 32;
+    }
+}
+
+// How many j chunks: enough workgroups for ~24 scheduling rounds of the chip, but chunks of at
+// least 8 tiles (4096 bodies) so the end-of-sweep reduction stays well under 1 % of the sweep.
+int auto_parts(const murbhip_ctx* c, int variant, unsigned long i_slots, unsigned long tiles)
+{
+    if (tiles == 0) return 0;
+    const unsigned long groups = (i_slots + variant_group(variant) - 1) / variant_group(variant);
+    const unsigned long want_blocks = (unsigned long)std::max(c->cu_count, 1) * 6ul * 24ul;
+    unsigned long parts = (want_blocks + groups - 1) / groups;
+    parts = std::min(parts, std::max(tiles / 8ul, 1ul));
+    parts = std::max(parts, 1ul);
+    return (int)std::min<unsigned long>(parts, kMaxParts / 2);
+}
+
+Plan make_plan(const murbhip_ctx* c)
+{
+    Plan p{};
+    p.variant = (c->variant >= 1 && c->variant <= kNumVariants) ? c->variant : kDefaultVariant;
+    const unsigned long tiles_local = c->slice / MURB_TILE_BODIES;
+    const unsigned long tiles_remote = (c->slots - c->slice) / MURB_TILE_BODIES;
+    if (c->world == 1) {
+        p.parts_local = c->jsplit > 0 ? std::min<int>(c->jsplit, (int)std::min<unsigned long>(tiles_local, kMaxParts))
+                                      : auto_parts(c, p.variant, c->slice, tiles_local);
+        p.parts_remote = 0;
+    } else {
+        // split the requested/auto chunk count between the two launches in proportion to their tiles
+        const unsigned long tiles_all = tiles_local + tiles_remote;
+        int total = c->jsplit > 0 ? c->jsplit : auto_parts(c, p.variant, c->slice, tiles_all);
+        total = std::max(total, 2);
+        int loc = (int)std::max<unsigned long>(1ul, (unsigned long)total * tiles_local / tiles_all);
+        int rem = std::max(1, total - loc);
+        p.parts_local = (int)std::min<unsigned long>((unsigned long)loc, std::min<unsigned long>(tiles_local, kMaxParts / 2));
+        p.parts_remote = (int)std::min<unsigned long>((unsigned long)rem, std::min<unsigned long>(tiles_remote, kMaxParts / 2));
+    }
+    return p;
+}
+
+int prof_begin(murbhip_ctx* c, Shard& sh)
+{
+    if (!c->profile) return 0;
+    if (sh.prof_used + 2 > sh.prof.size()) return 0;   // pool exhausted: stop sampling, keep running
+    return hip_rc(hipEventRecord(sh.prof[sh.prof_used], sh.compute));
+}
+int prof_end(murbhip_ctx* c, Shard& sh)
+{
+    if (!c->profile) return 0;
+    if (sh.prof_used + 2 > sh.prof.size()) return 0;
+    const int rc = hip_rc(hipEventRecord(sh.prof[sh.prof_used + 1], sh.compute));
+    sh.prof_used += 2;
+    return rc;
+}
+
+// Force over the tiles of `which` (0 = own slice / everything when world == 1, 1 = all but own slice).
+int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
+{
+    MurbForceArgs a{};
+    a.rec = sh.rec[c->cur];
+    a.accp = sh.accp;
+    a.i_first_slot = (int)((unsigned long)sh.rank * c->slice);
+    a.acc_stride = (unsigned int)c->slice;
+    a.soft2 = c->soft2;
+    const int tiles_local = (int)(c->slice / MURB_TILE_BODIES);
+    const int tiles_all = (int)(c->slots / MURB_TILE_BODIES);
+    if (which == 0) {
+        a.tiles = MurbTileRange{sh.rank * tiles_local, tiles_local, tiles_local, 0};
+        a.chunk_first = 0;
+        a.nchunks = p.parts_local;
+    } else {
+        a.tiles = MurbTileRange{0, tiles_all - tiles_local, sh.rank * tiles_local, tiles_local};
+        a.chunk_first = p.parts_local;
+        a.nchunks = p.parts_remote;
+    }
+    if (a.nchunks <= 0 || a.tiles.count <= 0) return 0;
+    const int i_slots = (int)sh.count;   // the grid rounds up to whole i groups; the extra slots hold mass 0
+    RC_TRY(prof_begin(c, sh));
+    RC_TRY(launch_force(p.variant, a, i_slots, sh.compute));
+    RC_TRY(prof_end(c, sh));
+    c->interactions_per_launch = (double)i_slots * (double)a.tiles.count * MURB_TILE_BODIES;
+    return 0;
+}
+
+int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int update_state)
+{
+    MurbIntegrateArgs a{};
+    a.rec_in = sh.rec[c->cur];
+    a.rec_out = sh.rec[c->cur ^ 1];
+    a.vel = sh.vel;
+    a.accp = sh.accp;
+    a.acc_out = sh.acc_out;
+    a.i_first_slot = (int)((unsigned long)sh.rank * c->slice);
+    a.count = (int)sh.count;
+    a.nparts = nparts;
+    a.acc_stride = (unsigned int)c->slice;
+    a.dt = dt;
+    a.update_state = update_state;
+    const unsigned pairs = (unsigned)(c->slice / 2);
+    hipLaunchKernelGGL(murb_integrate_kernel, dim3((pairs + 255) / 256), dim3(256), 0, sh.compute, a);
+    return hip_rc(hipGetLastError());
+}
+
+// Publish every shard's freshly integrated slice of rec[buf] to all shards (comm streams).
+int enqueue_exchange(murbhip_ctx* c, int buf)
+{
+    const size_t slice_f4 = c->slice;                  // float4 records per slice (1 per body slot)
+    const size_t slice_bytes = slice_f4 * sizeof(float4);
+    for (Shard& sh : c->shards) {
+        HIP_TRY(hipSetDevice(sh.device));
+        HIP_TRY(hipEventRecord(sh.ev_integrated, sh.compute));
+    }
+    if (c->exchange == 1) {
+        Rccl& r = rccl();
+        for (Shard& sh : c->shards) {
+            HIP_TRY(hipSetDevice(sh.device));
+            HIP_TRY(hipStreamWaitEvent(sh.comm, sh.ev_integrated, 0));
+        }
+        RC_TRY(nccl_rc(r.GroupStart()));
+        for (Shard& sh : c->shards) {
+            HIP_TRY(hipSetDevice(sh.device));
+            float4* base = sh.rec[buf];
+            RC_TRY(nccl_rc(r.AllGather(base + (size_t)sh.rank * slice_f4, base, slice_f4 * 4, kRcclFloat, sh.comm_rccl,
+                                       sh.comm)));
+        }
+        RC_TRY(nccl_rc(r.GroupEnd()));
+    } else {
+        // pull model: each shard copies every peer's slice out of the peer's buffer
+        for (Shard& sh : c->shards) {
+            HIP_TRY(hipSetDevice(sh.device));
+            for (Shard& peer : c->shards) {
+                if (&peer == &sh) continue;
+                HIP_TRY(hipStreamWaitEvent(sh.comm, peer.ev_integrated, 0));
+            }
+            HIP_TRY(hipStreamWaitEvent(sh.comm, sh.ev_integrated, 0));
+            for (Shard& peer : c->shards) {
+                if (&peer == &sh) continue;
+                const size_t off = (size_t)peer.rank * slice_f4;
+                if (peer.device == sh.device)
+                    HIP_TRY(hipMemcpyAsync(sh.rec[buf] + off, peer.rec[buf] + off, slice_bytes, hipMemcpyDeviceToDevice,
+                                           sh.comm));
+                else
+                    HIP_TRY(hipMemcpyPeerAsync(sh.rec[buf] + off, sh.device, peer.rec[buf] + off, peer.device, slice_bytes,
+                                               sh.comm));
+            }
+        }
+    }
+    for (Shard& sh : c->shards) {
+        HIP_TRY(hipSetDevice(sh.device));
+        HIP_TRY(hipEventRecord(sh.ev_gathered, sh.comm));
+    }
+    c->gather_pending = true;
+    return 0;
+}
+
+int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
+{
+    const Plan p = make_plan(c);
+    c->last_parts = p.parts_local + p.parts_remote;
+    for (Shard& sh : c->shards) {
+        HIP_TRY(hipSetDevice(sh.device));
+        if (c->world == 1) {
+            RC_TRY(enqueue_force(c, sh, p, 0));
+        } else if (c->overlap) {
+            RC_TRY(enqueue_force(c, sh, p, 0));   // own slice: written by our own integrate, already ordered
+            if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
+            RC_TRY(enqueue_force(c, sh, p, 1));
+        } else {
+            if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
+            RC_TRY(enqueue_force(c, sh, p, 0));
+            RC_TRY(enqueue_force(c, sh, p, 1));
+        }
+        RC_TRY(enqueue_integrate(c, sh, p.parts_local + p.parts_remote, dt, update_state));
+    }
+    if (update_state) {
+        if (c->world > 1) RC_TRY(enqueue_exchange(c, c->cur ^ 1));
+        c->cur ^= 1;
+    }
+    return 0;
+}
+
+int create_common(murbhip_ctx** out, unsigned long n, float soft, float g, int world, int nlocal, const int* devices,
+                  const int* ranks, int exchange, bool rank_mode)
+{
+    if (!out || n == 0 || world < 1 || nlocal < 1 || !(soft == soft)) return MURBHIP_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MURBHIP_E_NO_DEVICE;
+    for (int i = 0; i < nlocal; ++i)
+        if (devices[i] < 0 || devices[i] >= ndev) return MURBHIP_E_INVALID;
+    if (slice_slots(n, world) * (unsigned long)world > 0x7fffffffUL) return MURBHIP_E_INVALID;
+
+    murbhip_ctx* c = new (std::nothrow) murbhip_ctx;
+    if (!c) return MURBHIP_E_NOMEM;
+    c->n = n;
+    c->world = world;
+    c->slice = slice_slots(n, world);
+    c->slots = c->slice * (unsigned long)world;
+    c->soft2 = soft * soft;
+    c->g = g;
+    c->exchange = exchange;
+    c->rank_mode = rank_mode;
+    c->shards.resize(nlocal);
+
+    hipDeviceProp_t prop;
+    int rc = hip_rc(hipGetDeviceProperties(&prop, devices[0]));
+    if (rc == 0) { c->cu_count = prop.multiProcessorCount; c->clock_mhz = prop.clockRate / 1000; }
+
+    for (int i = 0; rc == 0 && i < nlocal; ++i) {
+        Shard& sh = c->shards[i];
+        sh.device = devices[i];
+        sh.rank = ranks[i];
+        partition(n, world, sh.rank, &sh.first, &sh.count);
+        if ((rc = hip_rc(hipSetDevice(sh.device)))) break;
+        if ((rc = hip_rc(hipStreamCreateWithFlags(&sh.compute, hipStreamNonBlocking)))) break;
+        if ((rc = hip_rc(hipStreamCreateWithFlags(&sh.comm, hipStreamNonBlocking)))) break;
+        if ((rc = hip_rc(hipEventCreateWithFlags(&sh.ev_integrated, hipEventDisableTiming)))) break;
+        if ((rc = hip_rc(hipEventCreateWithFlags(&sh.ev_gathered, hipEventDisableTiming)))) break;
+        const size_t rec_bytes = c->slots * sizeof(float4);
+        const size_t vel_bytes = c->slice * sizeof(float4);
+        const size_t accp_bytes = (size_t)kMaxParts * c->slice * sizeof(float4);
+        const size_t acco_bytes = 3 * c->slice * sizeof(float);
+        if ((rc = hip_rc(hipMalloc((void**)&sh.rec[0], rec_bytes)))) break;
+        if ((rc = hip_rc(hipMalloc((void**)&sh.rec[1], rec_bytes)))) break;
+        if ((rc = hip_rc(hipMalloc((void**)&sh.vel, vel_bytes)))) break;
+        if ((rc = hip_rc(hipMalloc((void**)&sh.accp, accp_bytes)))) break;
+        if ((rc = hip_rc(hipMalloc((void**)&sh.acc_out, acco_bytes)))) break;
+        if ((rc = hip_rc(hipMemset(sh.accp, 0, accp_bytes)))) break;
+        if ((rc = hip_rc(hipMemset(sh.acc_out, 0, acco_bytes)))) break;
+        sh.bytes = 2 * rec_bytes + vel_bytes + accp_bytes + acco_bytes;
+    }
+    // peer access for the copy exchange between distinct devices
+    if (rc == 0 && world > 1 && !rank_mode && exchange == 0) {
+        for (Shard& a : c->shards)
+            for (Shard& b : c->shards)
+                if (a.device != b.device) {
+                    int can = 0;
+                    hipSetDevice(a.device);
+                    if (hipDeviceCanAccessPeer(&can, a.device, b.device) == hipSuccess && can) {
+                        hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
+                        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) rc = hip_rc(e);
+                        (void)hipGetLastError();
+                    }
+                }
+    }
+    if (rc != 0) { murbhip_destroy(c); return rc; }
+    *out = c;
+    return 0;
+}
+
+// host SoA -> pair records for all slots
+void pack_records(const murbhip_ctx* c, const float* x, const float* y, const float* z, const float* w, float scale_w,
+                  bool w_present, unsigned long first_body, unsigned long nbodies, unsigned long first_slot,
+                  std::vector<float4>& out)
+{
+    // writes bodies [first_body, first_body + nbodies) at slots first_slot..; caller zero-fills `out`
+    for (unsigned long k = 0; k < nbodies; ++k) {
+        const unsigned long slot = first_slot + k, body = first_body + k;
+        const unsigned long ra = murb_rec_a(slot >> 1);
+        float* A = reinterpret_cast<float*>(&out[ra]);
+        float* B = reinterpret_cast<float*>(&out[ra + MURB_TILE_PAIRS]);
+        const int h = (int)(slot & 1);
+        A[h] = x[body];
+        A[2 + h] = y[body];
+        B[h] = z[body];
+        B[2 + h] = w_present ? scale_w * w[body] : 0.f;
+    }
+    (void)c;
+}
+
+}  // namespace
+
+// ===================================================================================== C ABI
+extern "C" {
+
+int murbhip_version(void) { return 100; }
+
+const char* murbhip_error_string(int code)
+{
+    static thread_local char buf[160];
+    if (code == 0) return "success";
+    if (code == MURBHIP_E_INVALID) return "murbhip: invalid argument";
+    if (code == MURBHIP_E_STATE) return "murbhip: call made in the wrong state (upload first?)";
+    if (code == MURBHIP_E_NO_DEVICE) return "murbhip: no usable HIP device";
+    if (code == MURBHIP_E_NO_RCCL) return "murbhip: librccl could not be loaded";
+    if (code == MURBHIP_E_NOMEM) return "murbhip: host allocation failed";
+    if (code <= -1000 && code > -2000) {
+        Rccl& r = rccl();
+        snprintf(buf, sizeof buf, "RCCL error %d: %s", -code - 1000,
+                 (r.ok && r.GetErrorString) ? r.GetErrorString(-code - 1000) : "?");
+        return buf;
+    }
+    if (code < 0 && code > -1000) {
+        snprintf(buf, sizeof buf, "HIP error %d: %s", -code, hipGetErrorString((hipError_t)(-code)));
+        return buf;
+    }
+    snprintf(buf, sizeof buf, "murbhip: unknown code %d", code);
+    return buf;
+}
+
+int murbhip_partition(unsigned long n, int world, int rank, unsigned long* first, unsigned long* count)
+{
+    if (world < 1 || rank < 0 || rank >= world || !first || !count) return MURBHIP_E_INVALID;
+    partition(n, world, rank, first, count);
+    return 0;
+}
+
+unsigned long murbhip_slice_slots(unsigned long n, int world) { return world < 1 ? 0 : slice_slots(n, world); }
+
+unsigned long murbhip_slot_of_body(unsigned long n, int world, unsigned long i)
+{
+    if (world < 1 || i >= n) return ~0ul;
+    const unsigned long base = n / (unsigned long)world, rem = n % (unsigned long)world;
+    // ranks < rem own base+1 bodies, the rest own base
+    unsigned long r, first;
+    if (i < rem * (base + 1)) { r = i / (base + 1); first = r * (base + 1); }
+    else { r = rem + (base ? (i - rem * (base + 1)) / base : 0); first = rem * (base + 1) + (r - rem) * base; }
+    return r * slice_slots(n, world) + (i - first);
+}
+
+int murbhip_device_count(int* count)
+{
+    if (!count) return MURBHIP_E_INVALID;
+    *count = 0;
+    return hip_rc(hipGetDeviceCount(count));
+}
+
+int murbhip_create(murbhip_ctx** out, unsigned long n, float soft, float g, int device)
+{
+    const int rank0 = 0;
+    return create_common(out, n, soft, g, 1, 1, &device, &rank0, 0, false);
+}
+
+int murbhip_create_sharded(murbhip_ctx** out, unsigned long n, float soft, float g, int ndev, const int* devices,
+                           int exchange)
+{
+    if (ndev < 1 || ndev > 64 || !devices || (exchange != 0 && exchange != 1)) return MURBHIP_E_INVALID;
+    if ((unsigned long)ndev > n) return MURBHIP_E_INVALID;
+    std::vector<int> ranks(ndev);
+    for (int i = 0; i < ndev; ++i) ranks[i] = i;
+    if (exchange == 1) {
+        if (!rccl().ok) return MURBHIP_E_NO_RCCL;
+    }
+    RC_TRY(create_common(out, n, soft, g, ndev, ndev, devices, ranks.data(), exchange, false));
+    if (exchange == 1 && ndev > 1) {
+        std::vector<rccl_comm_t> comms(ndev);
+        const int rc = nccl_rc(rccl().CommInitAll(comms.data(), ndev, devices));
+        if (rc != 0) { murbhip_destroy(*out); *out = nullptr; return rc; }
+        for (int i = 0; i < ndev; ++i) (*out)->shards[i].comm_rccl = comms[i];
+    }
+    return 0;
+}
+
+int murbhip_unique_id(void* id_out)
+{
+    if (!id_out) return MURBHIP_E_INVALID;
+    Rccl& r = rccl();
+    if (!r.ok) return MURBHIP_E_NO_RCCL;
+    rccl_id_t id;
+    RC_TRY(nccl_rc(r.GetUniqueId(&id)));
+    std::memcpy(id_out, &id, sizeof id);
+    return 0;
+}
+
+int murbhip_create_rank(murbhip_ctx** out, unsigned long n, float soft, float g, int device, int rank, int world,
+                        const void* unique_id)
+{
+    if (world < 1 || rank < 0 || rank >= world || (unsigned long)world > n) return MURBHIP_E_INVALID;
+    if (world > 1 && !unique_id) return MURBHIP_E_INVALID;
+    if (world > 1 && !rccl().ok) return MURBHIP_E_NO_RCCL;
+    RC_TRY(create_common(out, n, soft, g, world, 1, &device, &rank, 1, true));
+    if (world > 1) {
+        rccl_id_t id;
+        std::memcpy(&id, unique_id, sizeof id);
+        hipSetDevice(device);
+        const int rc = nccl_rc(rccl().CommInitRank(&(*out)->shards[0].comm_rccl, world, id, rank));
+        if (rc != 0) { murbhip_destroy(*out); *out = nullptr; return rc; }
+    }
+    return 0;
+}
+
+int murbhip_destroy(murbhip_ctx* c)
+{
+    if (!c) return 0;
+    for (Shard& sh : c->shards) {
+        hipSetDevice(sh.device);
+        if (sh.compute) hipStreamSynchronize(sh.compute);
+        if (sh.comm) hipStreamSynchronize(sh.comm);
+        if (sh.comm_rccl && rccl().ok) rccl().CommDestroy(sh.comm_rccl);
+        for (hipEvent_t e : sh.prof) hipEventDestroy(e);
+        if (sh.ev_integrated) hipEventDestroy(sh.ev_integrated);
+        if (sh.ev_gathered) hipEventDestroy(sh.ev_gathered);
+        if (sh.compute) hipStreamDestroy(sh.compute);
+        if (sh.comm) hipStreamDestroy(sh.comm);
+        hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out);
+    }
+    delete c;
+    return 0;
+}
+
+int murbhip_upload(murbhip_ctx* c, const float* qx, const float* qy, const float* qz, const float* vx, const float* vy,
+                   const float* vz, const float* m)
+{
+    if (!c || !qx || !qy || !qz || !vx || !vy || !vz || !m) return MURBHIP_E_INVALID;
+    RC_TRY(murbhip_sync(c));
+    // positions + GM for every slot (replicated), velocities for each local slice
+    std::vector<float4> rec(c->slots, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int r = 0; r < c->world; ++r) {
+        unsigned long first, count;
+        partition(c->n, c->world, r, &first, &count);
+        pack_records(c, qx, qy, qz, m, c->g, true, first, count, (unsigned long)r * c->slice, rec);
+    }
+    for (Shard& sh : c->shards) {
+        HIP_TRY(hipSetDevice(sh.device));
+        std::vector<float4> vel(c->slice, make_float4(0.f, 0.f, 0.f, 0.f));
+        pack_records(c, vx, vy, vz, nullptr, 0.f, false, sh.first, sh.count, 0, vel);
+        HIP_TRY(hipMemcpy(sh.rec[0], rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(sh.rec[1], rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(sh.vel, vel.data(), vel.size() * sizeof(float4), hipMemcpyHostToDevice));
+        sh.prof_used = 0;
+    }
+    c->cur = 0;
+    c->gather_pending = false;
+    c->uploaded = true;
+    return 0;
+}
+
+int murbhip_sync(murbhip_ctx* c)
+{
+    if (!c) return MURBHIP_E_INVALID;
+    int rc = 0;
+    for (Shard& sh : c->shards) {
+        int r1 = hip_rc(hipSetDevice(sh.device));
+        if (!r1) r1 = hip_rc(hipStreamSynchronize(sh.compute));
+        if (!r1) r1 = hip_rc(hipStreamSynchronize(sh.comm));
+        if (r1 && !rc) rc = r1;
+    }
+    if (rc && !c->async_error) c->async_error = rc;
+    return c->async_error ? c->async_error : rc;
+}
+
+int murbhip_download_state(murbhip_ctx* c, float* qx, float* qy, float* qz, float* vx, float* vy, float* vz)
+{
+    if (!c) return MURBHIP_E_INVALID;
+    if (!c->uploaded) return MURBHIP_E_STATE;
+    RC_TRY(murbhip_sync(c));
+    std::vector<float4> rec(c->slots), vel(c->slice);
+    // positions: any shard holds all of them once its exchange has landed (sync above)
+    {
+        Shard& sh = c->shards[0];
+        HIP_TRY(hipSetDevice(sh.device));
+        HIP_TRY(hipMemcpy(rec.data(), sh.rec[c->cur], rec.size() * sizeof(float4), hipMemcpyDeviceToHost));
+        for (int r = 0; r < c->world; ++r) {
+            unsigned long first, count;
+            partition(c->n, c->world, r, &first, &count);
+            for (unsigned long k = 0; k < count; ++k) {
+                const unsigned long slot = (unsigned long)r * c->slice + k;
+                const unsigned long ra = murb_rec_a(slot >> 1);
+                const float* A = reinterpret_cast<const float*>(&rec[ra]);
+                const float* B = reinterpret_cast<const float*>(&rec[ra + MURB_TILE_PAIRS]);
+                const int h = (int)(slot & 1);
+                if (qx) qx[first + k] = A[h];
+                if (qy) qy[first + k] = A[2 + h];
+                if (qz) qz[first + k] = B[h];
+            }
+        }
+    }
+    if (vx || vy || vz) {
+        for (Shard& sh : c->shards) {
+            HIP_TRY(hipSetDevice(sh.device));
+            HIP_TRY(hipMemcpy(vel.data(), sh.vel, vel.size() * sizeof(float4), hipMemcpyDeviceToHost));
+            for (unsigned long k = 0; k < sh.count; ++k) {
+                const unsigned long ra = murb_rec_a(k >> 1);
+                const float* A = reinterpret_cast<const float*>(&vel[ra]);
+                const float* B = reinterpret_cast<const float*>(&vel[ra + MURB_TILE_PAIRS]);
+                const int h = (int)(k & 1);
+                if (vx) vx[sh.first + k] = A[h];
+                if (vy) vy[sh.first + k] = A[2 + h];
+                if (vz) vz[sh.first + k] = B[h];
+            }
+        }
+    }
+    return 0;
+}
+
+int murbhip_download_acc(murbhip_ctx* c, float* ax, float* ay, float* az)
+{
+    if (!c || !ax || !ay || !az) return MURBHIP_E_INVALID;
+    if (!c->uploaded) return MURBHIP_E_STATE;
+    RC_TRY(murbhip_sync(c));
+    std::vector<float> a(3 * c->slice);
+    for (Shard& sh : c->shards) {
+        HIP_TRY(hipSetDevice(sh.device));
+        HIP_TRY(hipMemcpy(a.data(), sh.acc_out, a.size() * sizeof(float), hipMemcpyDeviceToHost));
+        std::memcpy(ax + sh.first, a.data(), sh.count * sizeof(float));
+        std::memcpy(ay + sh.first, a.data() + c->slice, sh.count * sizeof(float));
+        std::memcpy(az + sh.first, a.data() + 2 * c->slice, sh.count * sizeof(float));
+    }
+    return 0;
+}
+
+int murbhip_compute_acc(murbhip_ctx* c)
+{
+    if (!c) return MURBHIP_E_INVALID;
+    if (!c->uploaded) return MURBHIP_E_STATE;
+    return enqueue_iteration(c, 0.f, 0);
+}
+
+int murbhip_step(murbhip_ctx* c, float dt)
+{
+    if (!c) return MURBHIP_E_INVALID;
+    if (!c->uploaded) return MURBHIP_E_STATE;
+    return enqueue_iteration(c, dt, 1);
+}
+
+int murbhip_steps(murbhip_ctx* c, float dt, int iterations)
+{
+    if (!c || iterations < 0) return MURBHIP_E_INVALID;
+    if (!c->uploaded) return MURBHIP_E_STATE;
+    for (int i = 0; i < iterations; ++i) RC_TRY(enqueue_iteration(c, dt, 1));
+    return 0;
+}
+
+int murbhip_integrate_host_acc(murbhip_ctx* c, const float* ax, const float* ay, const float* az, float dt)
+{
+    if (!c || !ax || !ay || !az) return MURBHIP_E_INVALID;
+    if (!c->uploaded) return MURBHIP_E_STATE;
+    std::vector<float4> part(c->slice);
+    for (Shard& sh : c->shards) {
+        HIP_TRY(hipSetDevice(sh.device));
+        if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
+        std::fill(part.begin(), part.end(), make_float4(0.f, 0.f, 0.f, 0.f));
+        for (unsigned long k = 0; k < sh.count; ++k)
+            part[k] = make_float4(ax[sh.first + k], ay[sh.first + k], az[sh.first + k], 0.f);
+        HIP_TRY(hipMemcpyAsync(sh.accp, part.data(), part.size() * sizeof(float4), hipMemcpyHostToDevice, sh.compute));
+        HIP_TRY(hipStreamSynchronize(sh.compute));   // `part` is reused for the next shard
+        RC_TRY(enqueue_integrate(c, sh, 1, dt, 1));
+    }
+    if (c->world > 1) RC_TRY(enqueue_exchange(c, c->cur ^ 1));
+    c->cur ^= 1;
+    return 0;
+}
+
+int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
+{
+    if (!c || !key) return MURBHIP_E_INVALID;
+    const std::string k(key);
+    if (k == "variant") { if (value < 0 || value > kNumVariants) return MURBHIP_E_INVALID; c->variant = (int)value; }
+    else if (k == "jsplit") { if (value < 0 || value > kMaxParts / 2) return MURBHIP_E_INVALID; c->jsplit = (int)value; }
+    else if (k == "overlap") c->overlap = value ? 1 : 0;
+    else if (k == "profile") {
+        c->profile = value ? 1 : 0;
+        for (Shard& sh : c->shards) {
+            HIP_TRY(hipSetDevice(sh.device));
+            if (c->profile && sh.prof.empty()) {
+                sh.prof.resize(2 * kProfPairs);
+                for (hipEvent_t& e : sh.prof) HIP_TRY(hipEventCreate(&e));
+            }
+            sh.prof_used = 0;
+        }
+    } else return MURBHIP_E_INVALID;
+    return 0;
+}
+
+int murbhip_get_info(murbhip_ctx* c, const char* key, double* value)
+{
+    if (!c || !key || !value) return MURBHIP_E_INVALID;
+    const std::string k(key);
+    const Plan p = make_plan(c);
+    if (k == "cu_count") *value = c->cu_count;
+    else if (k == "clock_mhz") *value = c->clock_mhz;
+    else if (k == "n") *value = (double)c->n;
+    else if (k == "slots") *value = (double)c->slots;
+    else if (k == "world") *value = c->world;
+    else if (k == "rank") *value = c->shards[0].rank;
+    else if (k == "jsplit") *value = p.parts_local + p.parts_remote;
+    else if (k == "variant") *value = p.variant;
+    else if (k == "interactions_per_launch") *value = c->interactions_per_launch;
+    else if (k == "device_bytes") { double b = 0; for (Shard& sh : c->shards) b += (double)sh.bytes; *value = b; }
+    else if (k == "force_launches" || k == "force_ms_avg" || k == "force_ms_total") {
+        RC_TRY(murbhip_sync(c));
+        double total = 0; size_t launches = 0;
+        for (Shard& sh : c->shards) {
+            HIP_TRY(hipSetDevice(sh.device));
+            for (size_t i = 0; i + 1 < sh.prof_used; i += 2) {
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, sh.prof[i], sh.prof[i + 1]));
+                total += ms; ++launches;
+            }
+        }
+        if (k == "force_launches") *value = (double)launches;
+        else if (k == "force_ms_total") *value = total;
+        else *value = launches ? total / (double)launches : 0.0;
+    } else return MURBHIP_E_INVALID;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+"""ctypes binding of libmurbhip.so (include/murbhip.h) for tests/ and bench.py.
+
+This is plumbing only: the product's host side is the C++ mirror of the reference's plugin
+interface in nbody-eurohpc_amd/host/ (the reference is compiled C++).  There is no CPU fallback:
+importing works without a GPU (the library loads and the host-only helpers run), but every compute
+entry point raises MurbHipError when no MI355X is present or the library is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "..", "lib", "libmurbhip.so")
+G = np.float32(6.67384e-11)   # reference SimulationNBodyInterface.hpp:18
+
+_fp = C.POINTER(C.c_float)
+
+
+class MurbHipError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__(f"{what}: {error_string(code)} (code {code})")
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        path = os.path.normpath(LIB_PATH)
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} is missing: build it with `make -C nbody-eurohpc_amd` "
+                                    "(there is no CPU fallback for the HIP path)")
+        L = C.CDLL(path)
+        L.murbhip_version.restype = C.c_int
+        L.murbhip_error_string.restype = C.c_char_p
+        L.murbhip_error_string.argtypes = [C.c_int]
+        L.murbhip_partition.argtypes = [C.c_ulong, C.c_int, C.c_int, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]
+        L.murbhip_slice_slots.restype = C.c_ulong
+        L.murbhip_slice_slots.argtypes = [C.c_ulong, C.c_int]
+        L.murbhip_slot_of_body.restype = C.c_ulong
+        L.murbhip_slot_of_body.argtypes = [C.c_ulong, C.c_int, C.c_ulong]
+        L.murbhip_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.murbhip_create.argtypes = [C.POINTER(C.c_void_p), C.c_ulong, C.c_float, C.c_float, C.c_int]
+        L.murbhip_create_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_ulong, C.c_float, C.c_float, C.c_int,
+                                             C.POINTER(C.c_int), C.c_int]
+        L.murbhip_unique_id.argtypes = [C.c_void_p]
+        L.murbhip_create_rank.argtypes = [C.POINTER(C.c_void_p), C.c_ulong, C.c_float, C.c_float, C.c_int, C.c_int,
+                                          C.c_int, C.c_void_p]
+        L.murbhip_destroy.argtypes = [C.c_void_p]
+        L.murbhip_upload.argtypes = [C.c_void_p] + [_fp] * 7
+        L.murbhip_download_state.argtypes = [C.c_void_p] + [_fp] * 6
+        L.murbhip_download_acc.argtypes = [C.c_void_p] + [_fp] * 3
+        L.murbhip_compute_acc.argtypes = [C.c_void_p]
+        L.murbhip_step.argtypes = [C.c_void_p, C.c_float]
+        L.murbhip_steps.argtypes = [C.c_void_p, C.c_float, C.c_int]
+        L.murbhip_integrate_host_acc.argtypes = [C.c_void_p] + [_fp] * 3 + [C.c_float]
+        L.murbhip_sync.argtypes = [C.c_void_p]
+        L.murbhip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+        L.murbhip_get_info.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
+        _lib = L
+    return _lib
+
+
+EXPORTS = ("murbhip_version murbhip_error_string murbhip_partition murbhip_slice_slots murbhip_slot_of_body "
+           "murbhip_device_count murbhip_create murbhip_create_sharded murbhip_unique_id murbhip_create_rank "
+           "murbhip_destroy murbhip_upload murbhip_download_state murbhip_download_acc murbhip_compute_acc "
+           "murbhip_step murbhip_steps murbhip_integrate_host_acc murbhip_sync murbhip_set_option "
+           "murbhip_get_info").split()
+
+
+def error_string(code):
+    return lib().murbhip_error_string(code).decode()
+
+
+def _check(code, what):
+    if code != 0:
+        raise MurbHipError(code, what)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ------------------------------------------------------------------ host-only helpers
+def partition(n, world, rank):
+    first, count = C.c_ulong(), C.c_ulong()
+    _check(lib().murbhip_partition(n, world, rank, C.byref(first), C.byref(count)), "murbhip_partition")
+    return first.value, count.value
+
+
+def slice_slots(n, world):
+    return lib().murbhip_slice_slots(n, world)
+
+
+def slot_of_body(n, world, i):
+    return lib().murbhip_slot_of_body(n, world, i)
+
+
+def device_count():
+    c = C.c_int(0)
+    rc = lib().murbhip_device_count(C.byref(c))
+    return c.value if rc == 0 else 0
+
+
+def unique_id():
+    buf = C.create_string_buffer(128)
+    _check(lib().murbhip_unique_id(buf), "murbhip_unique_id")
+    return buf.raw
+
+
+class Simulation:
+    """One device-resident n-body state.  mode: single GPU (default), `devices=[...]` for one process
+    driving several shards, or `rank/world/uid` for one process per GPU."""
+
+    def __init__(self, n, soft=2e8, g=G, device=0, devices=None, exchange="copy", rank=None, world=None, uid=None):
+        self.n = int(n)
+        self._h = C.c_void_p()
+        L = lib()
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            _check(L.murbhip_create_sharded(C.byref(self._h), self.n, soft, g, len(devices), arr,
+                                            {"copy": 0, "rccl": 1}[exchange]), "murbhip_create_sharded")
+        elif rank is not None:
+            _check(L.murbhip_create_rank(C.byref(self._h), self.n, soft, g, device, rank, world, uid),
+                   "murbhip_create_rank")
+        else:
+            _check(L.murbhip_create(C.byref(self._h), self.n, soft, g, device), "murbhip_create")
+
+    # -- state
+    def upload(self, s):
+        a = [_f32(s[k]) for k in ("qx", "qy", "qz", "vx", "vy", "vz", "m")]
+        for x in a:
+            if x.shape[0] < self.n:
+                raise ValueError("state arrays shorter than n")
+        _check(lib().murbhip_upload(self._h, *[_ptr(x) for x in a]), "murbhip_upload")
+
+    def state(self):
+        out = {k: np.zeros(self.n, np.float32) for k in ("qx", "qy", "qz", "vx", "vy", "vz")}
+        _check(lib().murbhip_download_state(self._h, *[_ptr(out[k]) for k in ("qx", "qy", "qz", "vx", "vy", "vz")]),
+               "murbhip_download_state")
+        return out
+
+    def acc(self):
+        a = [np.zeros(self.n, np.float32) for _ in range(3)]
+        _check(lib().murbhip_download_acc(self._h, *[_ptr(x) for x in a]), "murbhip_download_acc")
+        return tuple(a)
+
+    # -- compute (enqueue only; sync() waits)
+    def compute_acc(self):
+        _check(lib().murbhip_compute_acc(self._h), "murbhip_compute_acc")
+
+    def step(self, dt=3600.0):
+        _check(lib().murbhip_step(self._h, dt), "murbhip_step")
+
+    def steps(self, dt, iterations):
+        _check(lib().murbhip_steps(self._h, dt, iterations), "murbhip_steps")
+
+    def integrate_host_acc(self, acc, dt):
+        a = [_f32(x) for x in acc]
+        _check(lib().murbhip_integrate_host_acc(self._h, *[_ptr(x) for x in a], dt), "murbhip_integrate_host_acc")
+
+    def sync(self):
+        _check(lib().murbhip_sync(self._h), "murbhip_sync")
+
+    # -- tuning / facts
+    def set_option(self, key, value):
+        _check(lib().murbhip_set_option(self._h, key.encode(), int(value)), f"murbhip_set_option({key})")
+
+    def info(self, key):
+        v = C.c_double()
+        _check(lib().murbhip_get_info(self._h, key.encode(), C.byref(v)), f"murbhip_get_info({key})")
+        return v.value
+
+    def close(self):
+        if self._h:
+            lib().murbhip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

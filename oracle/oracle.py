@@ -1,0 +1,226 @@
+"""TEST INFRASTRUCTURE — ctypes front end of the CPU oracle (oracle/_build/liboracle.so) and, when it
+has been built, of the real reference CPU path (oracle/_ref/libmurbref.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  The
+product (nbody-eurohpc_amd/) never does: it fails loudly when its HIP library is missing instead of
+falling back to anything in here.
+
+Reference citations (relative to /root/reference) are in murb_oracle.cpp / oracle_f64.cpp / ref_harness.cpp.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "_build", "liboracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libmurbref.so")
+
+G = np.float32(6.67384e-11)      # SimulationNBodyInterface.hpp:18
+SOFT = np.float32(2e8)           # main.cpp:47
+DT = np.float32(3600.0)          # main.cpp:45
+REF_SIMD_WIDTH = 4               # mipp::N<float>() of the reference build (no -march => SSE2)
+
+_f = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_d = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ul = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+FIELDS = ("qx", "qy", "qz", "vx", "vy", "vz", "m", "r")
+
+
+def build(ref=True):
+    """Compile the oracle (and, if /root/reference is present, the reference checker)."""
+    subprocess.run(["make", "-C", HERE, "all"] + (["ref"] if ref else []), check=True,
+                   stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            build(ref=os.path.isdir("/root/reference/src"))
+        L = C.CDLL(ORACLE_SO)
+        L.oracle_padding.restype = C.c_ulong
+        L.oracle_padding.argtypes = [C.c_ulong, C.c_int]
+        L.oracle_init.restype = None
+        L.oracle_init.argtypes = [C.c_ulong, C.c_char_p, C.c_ulong, C.c_int] + [_f] * 8
+        for name in ("oracle_accel_optim", "oracle_accel_naive"):
+            fn = getattr(L, name)
+            fn.restype = None
+            fn.argtypes = [C.c_ulong, _f, _f, _f, _f, C.c_float, _f, _f, _f]
+        L.oracle_integrate.restype = None
+        L.oracle_integrate.argtypes = [C.c_ulong] + [_f] * 9 + [C.c_float]
+        L.oracle_simulate.restype = None
+        L.oracle_simulate.argtypes = [C.c_int, C.c_ulong, C.c_int, C.c_float, C.c_float] + [_f] * 7 + [C.c_void_p]
+        L.oracle_accel_slice_f32.restype = None
+        L.oracle_accel_slice_f32.argtypes = [C.c_ulong, C.c_ulong, C.c_ulong, _f, _f, _f, _f, C.c_float, _f, _f, _f]
+        L.oracle_accel_f64.restype = None
+        L.oracle_accel_f64.argtypes = [C.c_ulong, C.c_ulong, C.c_ulong, _f, _f, _f, _f, C.c_float, _d, _d, _d]
+        L.oracle_accel_f64_subset.restype = None
+        L.oracle_accel_f64_subset.argtypes = [C.c_ulong, C.c_ulong, _ul, _f, _f, _f, _f, C.c_float, _d, _d, _d]
+        _lib = L
+    return _lib
+
+
+# ----------------------------------------------------------------------------- restated reference path
+def padding(n, simd_width=REF_SIMD_WIDTH):
+    return int(lib().oracle_padding(n, simd_width))
+
+
+def init_bodies(n, scheme="galaxy", seed=0, simd_width=REF_SIMD_WIDTH, with_padding=False):
+    """Initial conditions (Bodies.cpp:158-257).  Returns a dict of fp32 arrays of n entries
+    (n + padding with with_padding=True)."""
+    tot = n + padding(n, simd_width)
+    a = {k: np.zeros(tot, np.float32) for k in FIELDS}
+    lib().oracle_init(n, scheme.encode(), seed, simd_width, *[a[k] for k in FIELDS])
+    return a if with_padding else {k: v[:n].copy() for k, v in a.items()}
+
+
+def accel_optim(s, soft=SOFT):
+    n = len(s["qx"])
+    ax, ay, az = (np.zeros(n, np.float32) for _ in range(3))
+    lib().oracle_accel_optim(n, s["qx"], s["qy"], s["qz"], s["m"], soft, ax, ay, az)
+    return ax, ay, az
+
+
+def accel_naive(s, soft=SOFT):
+    n = len(s["qx"])
+    ax, ay, az = (np.zeros(n, np.float32) for _ in range(3))
+    lib().oracle_accel_naive(n, s["qx"], s["qy"], s["qz"], s["m"], soft, ax, ay, az)
+    return ax, ay, az
+
+
+def accel_slice_f32(s, i0, i1, soft=SOFT):
+    n = len(s["qx"])
+    ax, ay, az = (np.zeros(i1 - i0, np.float32) for _ in range(3))
+    lib().oracle_accel_slice_f32(n, i0, i1, s["qx"], s["qy"], s["qz"], s["m"], soft, ax, ay, az)
+    return ax, ay, az
+
+
+def accel_f64(s, soft=SOFT, i0=0, i1=None):
+    n = len(s["qx"])
+    i1 = n if i1 is None else i1
+    ax, ay, az = (np.zeros(i1 - i0, np.float64) for _ in range(3))
+    lib().oracle_accel_f64(n, i0, i1, s["qx"], s["qy"], s["qz"], s["m"], soft, ax, ay, az)
+    return ax, ay, az
+
+
+def accel_f64_subset(s, idx, soft=SOFT):
+    n = len(s["qx"])
+    idx = np.ascontiguousarray(idx, dtype=np.uint64)
+    ax, ay, az = (np.zeros(len(idx), np.float64) for _ in range(3))
+    lib().oracle_accel_f64_subset(n, len(idx), idx, s["qx"], s["qy"], s["qz"], s["m"], soft, ax, ay, az)
+    return ax, ay, az
+
+
+def integrate(s, acc, dt=DT):
+    """In-place position/velocity update (Bodies.cpp:260-278)."""
+    ax, ay, az = (np.ascontiguousarray(a, np.float32) for a in acc)
+    lib().oracle_integrate(len(s["qx"]), s["qx"], s["qy"], s["qz"], s["vx"], s["vy"], s["vz"], ax, ay, az, dt)
+
+
+def simulate(s, iterations, variant="cpu+optim", soft=SOFT, dt=DT):
+    """`iterations` whole steps in place; returns the last step's accelerations."""
+    n = len(s["qx"])
+    acc = np.zeros(3 * n, np.float32)
+    lib().oracle_simulate({"cpu+optim": 0, "cpu+naive": 1}[variant], n, iterations, soft, dt, s["qx"], s["qy"],
+                          s["qz"], s["vx"], s["vy"], s["vz"], s["m"], acc.ctypes.data_as(C.c_void_p))
+    return acc[:n], acc[n:2 * n], acc[2 * n:]
+
+
+def rel_err(test, ref):
+    """Per-body relative vector error |a_test - a_ref| / |a_ref| (the metric of SURVEY.md §8c)."""
+    t = np.stack([np.asarray(c, np.float64) for c in test])
+    r = np.stack([np.asarray(c, np.float64) for c in ref])
+    num = np.sqrt(((t - r) ** 2).sum(0))
+    den = np.sqrt((r ** 2).sum(0))
+    return num / np.maximum(den, np.finfo(np.float64).tiny)
+
+
+# ----------------------------------------------------------------------------- the real reference (checker only)
+_ref = None
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        if not have_ref():
+            raise FileNotFoundError(REF_SO + " not built (make -C oracle ref needs /root/reference)")
+        L = C.CDLL(REF_SO)
+        L.murbref_create.restype = C.c_void_p
+        L.murbref_create.argtypes = [C.c_char_p, C.c_ulong, C.c_char_p, C.c_float, C.c_float]
+        L.murbref_destroy.argtypes = [C.c_void_p]
+        L.murbref_n.restype = C.c_ulong
+        L.murbref_n.argtypes = [C.c_void_p]
+        L.murbref_padding.restype = C.c_ulong
+        L.murbref_padding.argtypes = [C.c_void_p]
+        L.murbref_flops_per_ite.restype = C.c_float
+        L.murbref_flops_per_ite.argtypes = [C.c_void_p]
+        L.murbref_allocated_bytes.restype = C.c_float
+        L.murbref_allocated_bytes.argtypes = [C.c_void_p]
+        L.murbref_step.argtypes = [C.c_void_p, C.c_int]
+        L.murbref_get_state.argtypes = [C.c_void_p] + [_f] * 8
+        L.murbref_get_acc.restype = C.c_int
+        L.murbref_get_acc.argtypes = [C.c_void_p, _f, _f, _f]
+        L.murbref_integrate.argtypes = [C.c_ulong, C.c_char_p, _f, _f, _f, C.c_float, C.c_int] + [_f] * 6
+        _ref = L
+    return _ref
+
+
+class RefSim:
+    """One of the reference's own CPU implementations (--im cpu+naive|cpu+optim|cpu+simd|cpu+omp)."""
+
+    def __init__(self, tag, n, scheme="galaxy", soft=SOFT, dt=DT):
+        self.L = ref_lib()
+        self.h = self.L.murbref_create(tag.encode(), n, scheme.encode(), soft, dt)
+        if not self.h:
+            raise ValueError("unknown reference implementation tag " + tag)
+        self.n = int(self.L.murbref_n(self.h))
+        self.padding = int(self.L.murbref_padding(self.h))
+
+    def step(self, iterations=1):
+        self.L.murbref_step(self.h, iterations)
+
+    def state(self, with_padding=False):
+        tot = self.n + self.padding
+        a = {k: np.zeros(tot, np.float32) for k in FIELDS}
+        self.L.murbref_get_state(self.h, *[a[k] for k in FIELDS])
+        return a if with_padding else {k: v[:self.n].copy() for k, v in a.items()}
+
+    def acc(self):
+        ax, ay, az = (np.zeros(self.n, np.float32) for _ in range(3))
+        if self.L.murbref_get_acc(self.h, ax, ay, az) != 0:
+            raise RuntimeError("implementation exposes no accelerations")
+        return ax, ay, az
+
+    def flops_per_ite(self):
+        return float(self.L.murbref_flops_per_ite(self.h))
+
+    def allocated_bytes(self):
+        return float(self.L.murbref_allocated_bytes(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.murbref_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ref_integrate(n, scheme, acc, dt, steps):
+    """Reference Bodies::updatePositionsAndVelocities driven with given accelerations."""
+    out = {k: np.zeros(n, np.float32) for k in FIELDS[:6]}
+    ax, ay, az = (np.ascontiguousarray(a, np.float32) for a in acc)
+    ref_lib().murbref_integrate(n, scheme.encode(), ax, ay, az, dt, steps, *[out[k] for k in FIELDS[:6]])
+    return out
