@@ -221,7 +221,6 @@ __global__ __launch_bounds__(WAVES * 64) void murb_force_kernel(const MurbForceA
 // Reference semantics, Bodies.cpp:260-278 (= CUDABodies.cu:126-153):
 //     aDt = a*dt (fp32);  q' = q + (v + aDt*0.5)*dt with the parenthesis and the add evaluated in
 //     fp64 (the literal 0.5 is a double) and rounded once to fp32;  v' = v + aDt (fp32).
-// The _rn intrinsics keep hipcc from contracting these into FMAs, which would change the rounding.
 struct MurbIntegrateArgs {
     const float4* rec_in;    // all slots
     float4* rec_out;         // all slots (other buffer); only the local slice is written
@@ -236,15 +235,33 @@ struct MurbIntegrateArgs {
     int update_state;        // 0: only reduce partial sums into acc_out
 };
 
+// `#pragma clang fp contract(off)`: hipcc contracts a*b+c into one FMA by default (also through the
+// __fmul_rn/__fadd_rn wrappers, which are plain operators in HIP); the reference's x86 build has no
+// FMA, so every product here must be rounded on its own or v' = v + a*dt is off by up to 15 ulp.
 __device__ __forceinline__ float murb_drift(float q, float v, float a_dt, float dt)
 {
-    const double half_kick = __dmul_rn((double)a_dt, 0.5);
-    const double vel_mid = __dadd_rn((double)v, half_kick);
-    return (float)__dadd_rn((double)q, __dmul_rn(vel_mid, (double)dt));
+#pragma clang fp contract(off)
+    const double half_kick = (double)a_dt * 0.5;
+    const double vel_mid = (double)v + half_kick;
+    const double moved = vel_mid * (double)dt;
+    return (float)((double)q + moved);
+}
+
+__device__ __forceinline__ float murb_kick(float a, float dt)
+{
+#pragma clang fp contract(off)
+    return a * dt;
+}
+
+__device__ __forceinline__ float murb_add_rounded(float v, float a_dt)
+{
+#pragma clang fp contract(off)
+    return v + a_dt;
 }
 
 __global__ __launch_bounds__(256) void murb_integrate_kernel(const MurbIntegrateArgs a)
 {
+#pragma clang fp contract(off)
     const int lp = blockIdx.x * blockDim.x + threadIdx.x;   // local pair
     const int s0 = 2 * lp;                                    // local slots s0, s0+1
     if (s0 >= (int)a.acc_stride) return;
@@ -268,14 +285,14 @@ __global__ __launch_bounds__(256) void murb_integrate_kernel(const MurbIntegrate
     float4 VA = a.vel[va], VB = a.vel[va + MURB_TILE_PAIRS];
     const float dt = a.dt;
     if (s0 < a.count) {
-        const float kx = __fmul_rn(acc0.x, dt), ky = __fmul_rn(acc0.y, dt), kz = __fmul_rn(acc0.z, dt);
+        const float kx = murb_kick(acc0.x, dt), ky = murb_kick(acc0.y, dt), kz = murb_kick(acc0.z, dt);
         A.x = murb_drift(A.x, VA.x, kx, dt); A.z = murb_drift(A.z, VA.z, ky, dt); B.x = murb_drift(B.x, VB.x, kz, dt);
-        VA.x = __fadd_rn(VA.x, kx); VA.z = __fadd_rn(VA.z, ky); VB.x = __fadd_rn(VB.x, kz);
+        VA.x = murb_add_rounded(VA.x, kx); VA.z = murb_add_rounded(VA.z, ky); VB.x = murb_add_rounded(VB.x, kz);
     }
     if (s0 + 1 < a.count) {
-        const float kx = __fmul_rn(acc1.x, dt), ky = __fmul_rn(acc1.y, dt), kz = __fmul_rn(acc1.z, dt);
+        const float kx = murb_kick(acc1.x, dt), ky = murb_kick(acc1.y, dt), kz = murb_kick(acc1.z, dt);
         A.y = murb_drift(A.y, VA.y, kx, dt); A.w = murb_drift(A.w, VA.w, ky, dt); B.y = murb_drift(B.y, VB.y, kz, dt);
-        VA.y = __fadd_rn(VA.y, kx); VA.w = __fadd_rn(VA.w, ky); VB.y = __fadd_rn(VB.y, kz);
+        VA.y = murb_add_rounded(VA.y, kx); VA.w = murb_add_rounded(VA.w, ky); VB.y = murb_add_rounded(VB.y, kz);
     }
     a.rec_out[ra] = A; a.rec_out[ra + MURB_TILE_PAIRS] = B;
     a.vel[va] = VA; a.vel[va + MURB_TILE_PAIRS] = VB;

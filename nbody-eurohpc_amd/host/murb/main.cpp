@@ -1,0 +1,192 @@
+// murb-hip: a murb-compatible driver for the MI355X implementations.  The reference's own
+// src/murb/main.cpp cannot be built without MPI/OpenGL, so this restates the part of it that the
+// benchmark command lines use (README.md:54-102): same flags, same configuration banner, same
+// iteration loop and timing window, same final line
+//     Entire simulation took <ms> ms (<fps> FPS, <gflops> Gflop/s)
+// (reference main.cpp:61-165 flags, :205-270 factory, :323-334 banner, :348-398 loop and summary).
+//
+// A maintainer of the reference adds the HIP path to the real driver with one branch in
+// createImplem() — see INTEGRATION.md; the branch below is that code.
+#include <cstdlib>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "core/Bodies.hpp"
+#include "core/BodiesAllocator.hpp"
+#include "implem/SimulationNBodyHIP.hpp"
+#include "murbhip.h"
+#include "utils/ArgumentsReader.hpp"
+#include "utils/Perf.hpp"
+
+// same globals and defaults as the reference (main.cpp:38-52)
+unsigned long NBodies;
+unsigned long NIterations;
+std::string ImplTag = "hip+tile";
+bool Verbose = false;
+bool GSEnable = true;
+bool VisuEnable = true;
+float Dt = 3600;
+float Softening = 2e+08;
+std::string BodiesScheme = "galaxy";
+bool ShowGFlops = false;
+int NDevices = 0;        // --ngpu, hip+tile+multi only (0 = all visible)
+bool FreeRunning = false;   // --free: sync once at the end instead of once per iteration
+
+static void argsReader(int argc, char **argv)
+{
+    std::map<std::string, std::string> reqArgs, faculArgs, docArgs;
+    Arguments_reader reader(argc, argv);
+    reqArgs["n"] = "nBodies";          docArgs["n"] = "the number of generated bodies.";
+    reqArgs["i"] = "nIterations";      docArgs["i"] = "the number of iterations to compute.";
+    faculArgs["v"] = "";               docArgs["v"] = "enable verbose mode.";
+    faculArgs["h"] = "";               docArgs["h"] = "display this help.";
+    faculArgs["-help"] = "";           docArgs["-help"] = "display this help.";
+    faculArgs["-dt"] = "timeStep";     docArgs["-dt"] = "select a fixed time step in second (default is " + std::to_string(Dt) + " sec).";
+    faculArgs["-ngs"] = "";            docArgs["-ngs"] = "accepted for compatibility (no visualization in this driver).";
+    faculArgs["-nv"] = "";             docArgs["-nv"] = "no visualization (always the case here).";
+    faculArgs["-nvc"] = "";            docArgs["-nvc"] = "accepted for compatibility.";
+    faculArgs["-ww"] = "winWidth";     docArgs["-ww"] = "accepted for compatibility.";
+    faculArgs["-wh"] = "winHeight";    docArgs["-wh"] = "accepted for compatibility.";
+    faculArgs["-im"] = "ImplTag";
+    docArgs["-im"] = "code implementation tag:\n"
+                     "\t\t\t - \"hip+tile\"        one MI355X, device-resident bodies\n"
+                     "\t\t\t - \"hip+tile+multi\"  bodies partitioned over --ngpu MI355X, RCCL position exchange\n"
+                     "\t\t\t ----";
+    faculArgs["-soft"] = "softeningFactor"; docArgs["-soft"] = "softening factor.";
+    faculArgs["s"] = "bodies scheme";  docArgs["s"] = "bodies scheme (initial conditions can be \"galaxy\" or \"random\").";
+    faculArgs["-gf"] = "";             docArgs["-gf"] = "display the number of GFlop/s.";
+    faculArgs["-ngpu"] = "nGpus";      docArgs["-ngpu"] = "number of GPUs for hip+tile+multi (default: all visible).";
+    faculArgs["-free"] = "";           docArgs["-free"] = "free-running timing: one device sync at the end, not one per iteration.";
+
+    const bool ok = reader.parse_arguments(reqArgs, faculArgs);
+    if (!ok || reader.exist_argument("h") || reader.exist_argument("-help")) {
+        if (reader.parse_doc_args(docArgs)) reader.print_usage();
+        else std::cout << "A problem was encountered when parsing arguments documentation... exiting." << std::endl;
+        exit(-1);
+    }
+    NBodies = stoi(reader.get_argument("n"));
+    NIterations = stoi(reader.get_argument("i"));
+    if (reader.exist_argument("v")) Verbose = true;
+    if (reader.exist_argument("-dt")) Dt = stof(reader.get_argument("-dt"));
+    if (reader.exist_argument("-ngs")) GSEnable = false;
+    if (reader.exist_argument("-nv")) VisuEnable = false;
+    if (reader.exist_argument("-im")) ImplTag = reader.get_argument("-im");
+    if (reader.exist_argument("-soft")) {
+        Softening = stof(reader.get_argument("-soft"));
+        if (Softening == 0.f) {
+            std::cout << "Softening factor can't be equal to 0... exiting." << std::endl;
+            exit(-1);
+        }
+    }
+    if (reader.exist_argument("s")) BodiesScheme = reader.get_argument("s");
+    if (reader.exist_argument("-gf")) ShowGFlops = true;
+    if (reader.exist_argument("-ngpu")) NDevices = stoi(reader.get_argument("-ngpu"));
+    if (reader.exist_argument("-free")) FreeRunning = true;
+}
+
+// "..d ..h ..m ..s" (main.cpp:175-196)
+static std::string strDate(float timestamp)
+{
+    const unsigned days = timestamp / 86400.f;
+    float rest = timestamp - days * 86400.f;
+    const unsigned hours = rest / 3600.f;
+    rest -= hours * 3600.f;
+    const unsigned minutes = rest / 60.f;
+    rest -= minutes * 60.f;
+    std::stringstream res;
+    res << std::fixed << std::setprecision(0) << std::setw(4) << days << "d " << std::setw(4) << hours << "h "
+        << std::setw(4) << minutes << "m " << std::setprecision(3) << std::setw(5) << rest << "s";
+    return res.str();
+}
+
+template <typename T> static SimulationNBodyHIP<T> *createImplem()
+{
+    if (ImplTag == "hip+tile") {
+        HIPBodiesAllocator<T> hipAllocator(NBodies, BodiesScheme);
+        return new SimulationNBodyHIP<T>(hipAllocator, Softening);
+    }
+    if (ImplTag == "hip+tile+multi") {
+        int visible = 0;
+        murbhipCheck(murbhip_device_count(&visible), "murbhip_device_count");
+        const int use = NDevices > 0 ? NDevices : visible;
+        std::vector<int> devices(use);
+        for (int d = 0; d < use; ++d) devices[d] = d % (visible > 0 ? visible : 1);
+        HIPBodiesAllocator<T> hipAllocator(NBodies, BodiesScheme);
+        return new SimulationNBodyHIP<T>(hipAllocator, Softening, devices, /*exchange: RCCL when distinct GPUs*/
+                                         use <= visible ? 1 : 0);
+    }
+    std::cout << "Implementation '" << ImplTag << "' does not exist... Exiting." << std::endl;
+    exit(-1);
+}
+
+int main(int argc, char **argv)
+{
+    argsReader(argc, argv);
+    SimulationNBodyHIP<float> *simu = createImplem<float>();
+    NBodies = simu->getBodies()->getN();
+    const float Mbytes = simu->getAllocatedBytes() / 1024.f / 1024.f;
+
+    std::cout << "n-body simulation configuration:" << std::endl;
+    std::cout << "--------------------------------" << std::endl;
+    std::cout << "  -> bodies scheme     (-s    ): " << BodiesScheme << std::endl;
+    std::cout << "  -> implementation    (--im  ): " << ImplTag << std::endl;
+    std::cout << "  -> nb. of bodies     (-n    ): " << NBodies << std::endl;
+    std::cout << "  -> nb. of iterations (-i    ): " << NIterations << std::endl;
+    std::cout << "  -> verbose mode      (-v    ): " << ((Verbose) ? "enable" : "disable") << std::endl;
+    std::cout << "  -> precision                 : " << "fp32" << std::endl;
+    std::cout << "  -> mem. allocated            : " << Mbytes << " MB" << std::endl;
+    std::cout << "  -> geometry shader   (--ngs ): " << ((GSEnable) ? "enable" : "disable") << std::endl;
+    std::cout << "  -> time step         (--dt  ): " << std::to_string(Dt) + " sec" << std::endl;
+    std::cout << "  -> softening factor  (--soft): " << Softening << std::endl;
+
+    simu->setDt(Dt);
+    std::cout << "Simulation started..." << std::endl;
+
+    // Timed region = computeOneIteration() + the driver's device sync, once per iteration
+    // (main.cpp:353-371).  --free moves the sync after the loop (not a mode of the reference).
+    Perf perfIte, perfTotal;
+    float physicTime = 0.f;
+    unsigned long iIte;
+    if (FreeRunning) perfIte.start();
+    for (iIte = 1; iIte <= NIterations; iIte++) {
+        if (!FreeRunning) perfIte.start();
+        simu->computeOneIteration();
+        if (!FreeRunning) {
+            simu->synchronize();
+            perfIte.stop();
+            perfTotal += perfIte;
+        }
+        physicTime += simu->getDt();
+        if (Verbose && !FreeRunning) {
+            std::stringstream gflops;
+            if (ShowGFlops)
+                gflops << ", " << std::setprecision(1) << std::fixed << std::setw(6)
+                       << perfTotal.getGflops(simu->getFlopsPerIte() * iIte) << " Gflop/s";
+            std::cout << "Iteration n°" << std::setw(4) << iIte << " (" << std::setprecision(1) << std::fixed
+                      << std::setw(6) << perfTotal.getFPS(iIte) << " FPS" << gflops.str()
+                      << "), physic time: " << strDate(physicTime) << "\r";
+            if (iIte % 5 == 0) std::cout << std::flush;
+        }
+    }
+    if (FreeRunning) {
+        simu->synchronize();
+        perfIte.stop();
+        perfTotal += perfIte;
+    }
+    if (Verbose) std::cout << std::endl;
+    std::cout << "Simulation ended." << std::endl << std::endl;
+
+    std::stringstream gflops;
+    if (ShowGFlops)
+        gflops << ", " << std::setprecision(1) << std::fixed << std::setw(6)
+               << perfTotal.getGflops(simu->getFlopsPerIte() * (iIte - 1)) << " Gflop/s";
+    std::cout << "Entire simulation took " << perfTotal.getElapsedTime() << " ms "
+              << "(" << perfTotal.getFPS(iIte - 1) << " FPS" << gflops.str() << ")" << std::endl;
+
+    delete simu;
+    return EXIT_SUCCESS;
+}

@@ -195,3 +195,104 @@ class Simulation:
             self.close()
         except Exception:
             pass
+
+
+# ====================================================================== host mirror (libmurbhost.so)
+# The C++ mirror of the reference's plugin interface (nbody-eurohpc_amd/host/), reached through
+# host/capi.cpp.  It provides the product's own initial conditions and lets tests drive
+# SimulationNBodyHIP / HIPBodies the way the reference's Catch2 tests drive their CUDA twins.
+HOST_LIB_PATH = os.path.join(_HERE, "..", "lib", "libmurbhost.so")
+FIELDS = ("qx", "qy", "qz", "vx", "vy", "vz", "m", "r")
+_host = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        lib()   # libmurbhost.so depends on libmurbhip.so: load it first (same directory, via rpath too)
+        path = os.path.normpath(HOST_LIB_PATH)
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} is missing: build it with `make -C nbody-eurohpc_amd`")
+        H = C.CDLL(path)
+        H.murbhost_padding.restype = C.c_ulong
+        H.murbhost_padding.argtypes = [C.c_ulong, C.c_char_p]
+        H.murbhost_init_bodies.argtypes = [C.c_ulong, C.c_char_p, C.c_ulong] + [_fp] * 8
+        H.murbhost_integrate.argtypes = [C.c_ulong, C.c_char_p, _fp, _fp, _fp, C.c_float, C.c_int, C.c_int] + [_fp] * 6
+        H.murbhost_sim_create.restype = C.c_void_p
+        H.murbhost_sim_create.argtypes = [C.c_ulong, C.c_char_p, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_int),
+                                          C.c_int]
+        H.murbhost_sim_destroy.argtypes = [C.c_void_p]
+        H.murbhost_sim_step.argtypes = [C.c_void_p, C.c_int]
+        H.murbhost_sim_n.restype = C.c_ulong
+        H.murbhost_sim_n.argtypes = [C.c_void_p]
+        H.murbhost_sim_flops_per_ite.restype = C.c_float
+        H.murbhost_sim_flops_per_ite.argtypes = [C.c_void_p]
+        H.murbhost_sim_allocated_bytes.restype = C.c_float
+        H.murbhost_sim_allocated_bytes.argtypes = [C.c_void_p]
+        H.murbhost_sim_state.argtypes = [C.c_void_p] + [_fp] * 8
+        H.murbhost_sim_acc.argtypes = [C.c_void_p] + [_fp] * 3
+        _host = H
+    return _host
+
+
+def host_padding(n, scheme="galaxy"):
+    return int(host_lib().murbhost_padding(n, scheme.encode()))
+
+
+def init_bodies(n, scheme="galaxy", seed=0, with_padding=False):
+    """The product's initial conditions: host/core/Bodies.cpp (mirror of reference Bodies.cpp:158-257)."""
+    tot = n + host_padding(n, scheme)
+    a = {k: np.zeros(tot, np.float32) for k in FIELDS}
+    host_lib().murbhost_init_bodies(n, scheme.encode(), seed, *[_ptr(a[k]) for k in FIELDS])
+    return a if with_padding else {k: v[:n].copy() for k, v in a.items()}
+
+
+def host_integrate(n, scheme, acc, dt, steps, on_device=False):
+    """Bodies / HIPBodies ::updatePositionsAndVelocities(accSoA, dt) applied `steps` times."""
+    out = {k: np.zeros(n, np.float32) for k in FIELDS[:6]}
+    a = [_f32(x) for x in acc]
+    host_lib().murbhost_integrate(n, scheme.encode(), *[_ptr(x) for x in a], dt, steps, int(on_device),
+                                  *[_ptr(out[k]) for k in FIELDS[:6]])
+    return out
+
+
+class HostSim:
+    """SimulationNBodyHIP<float> behind HIPBodiesAllocator<float> — the `--im hip+tile[+multi]` plugin."""
+
+    def __init__(self, n, scheme="galaxy", soft=2e8, dt=3600.0, devices=(0,), exchange="rccl"):
+        arr = (C.c_int * len(devices))(*devices)
+        self.H = host_lib()
+        self.h = self.H.murbhost_sim_create(n, scheme.encode(), soft, dt, len(devices), arr,
+                                            {"copy": 0, "rccl": 1}[exchange])
+        self.n = int(self.H.murbhost_sim_n(self.h))
+
+    def step(self, iterations=1):
+        self.H.murbhost_sim_step(self.h, iterations)
+
+    def state(self):
+        pad = 0
+        a = {k: np.zeros(self.n + 64, np.float32) for k in FIELDS}   # room for SIMD padding bodies
+        self.H.murbhost_sim_state(self.h, *[_ptr(a[k]) for k in FIELDS])
+        return {k: v[:self.n].copy() for k, v in a.items()}
+
+    def acc(self):
+        a = [np.zeros(self.n, np.float32) for _ in range(3)]
+        self.H.murbhost_sim_acc(self.h, *[_ptr(x) for x in a])
+        return tuple(a)
+
+    def flops_per_ite(self):
+        return float(self.H.murbhost_sim_flops_per_ite(self.h))
+
+    def allocated_bytes(self):
+        return float(self.H.murbhost_sim_allocated_bytes(self.h))
+
+    def close(self):
+        if self.h:
+            self.H.murbhost_sim_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

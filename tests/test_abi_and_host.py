@@ -1,0 +1,130 @@
+"""CPU: the C-ABI library loads and exports everything include/murbhip.h declares; host-only entry
+points behave; the C++ host mirror (Bodies) reproduces the reference's initial conditions and
+integrator bit for bit (fixtures from the compiled reference).  No compute call needs a GPU here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def mh():
+    import murbhip
+    murbhip.lib()
+    return murbhip
+
+
+def test_every_declared_symbol_is_exported(mh):
+    header = open(os.path.join(ROOT, "include", "murbhip.h")).read()
+    declared = sorted(set(re.findall(r"\b(murbhip_[a-z_0-9]+)\s*\(", header)))
+    assert declared == sorted(mh.EXPORTS), "python binding list out of date with the header"
+    L = mh.lib()
+    for name in declared:
+        assert hasattr(L, name), name + " declared in include/murbhip.h but not exported"
+    nm = subprocess.run(["nm", "-D", "--defined-only", os.path.normpath(mh.LIB_PATH)], capture_output=True, text=True)
+    exported = set(re.findall(r" T (murbhip_[a-z_0-9]+)", nm.stdout))
+    assert exported == set(declared), exported ^ set(declared)
+    assert L.murbhip_version() == 100
+
+
+def test_no_oracle_in_product(mh):
+    """The shipped libraries must not link or reference anything under oracle/."""
+    for lib in ("libmurbhip.so", "libmurbhost.so"):
+        path = os.path.join(ROOT, "nbody-eurohpc_amd", "lib", lib)
+        out = subprocess.run(["ldd", path], capture_output=True, text=True).stdout
+        assert "oracle" not in out and "murbref" not in out
+        assert b"liboracle" not in open(path, "rb").read()
+
+
+@pytest.mark.parametrize("n,world", [(30000, 4), (200000, 8), (2049, 2), (2049, 3), (7, 8), (1000000, 8), (5, 1)])
+def test_partition_is_the_reference_rule(mh, n, world):
+    """counts[r] = n/world + (r < n%world), displs = prefix sums (SimulationNBodyMultiNode.cpp:76-91)."""
+    first = 0
+    for r in range(world):
+        f, c = mh.partition(n, world, r)
+        assert c == n // world + (1 if r < n % world else 0)
+        assert f == first
+        first += c
+    assert first == n
+    slots = mh.slice_slots(n, world)
+    assert slots % 512 == 0 and slots >= mh.partition(n, world, 0)[1] and slots - 512 < max(mh.partition(n, world, 0)[1], 1)
+    for i in {0, n // 2, n - 1, min(n - 1, n // world), min(n - 1, n // world + 1)}:
+        s = mh.slot_of_body(n, world, i)
+        r = s // slots
+        f, c = mh.partition(n, world, r)
+        assert f <= i < f + c and s - r * slots == i - f
+
+
+def test_host_entry_points_reject_bad_arguments(mh):
+    L = mh.lib()
+    f, c = C.c_ulong(), C.c_ulong()
+    assert L.murbhip_partition(10, 0, 0, C.byref(f), C.byref(c)) == -2000
+    assert L.murbhip_partition(10, 2, 2, C.byref(f), C.byref(c)) == -2000
+    assert "invalid" in mh.error_string(-2000)
+    assert mh.error_string(0) == "success"
+    assert "HIP error" in mh.error_string(-1)
+    assert L.murbhip_sync(None) == -2000
+    assert L.murbhip_step(None, 1.0) == -2000
+    assert L.murbhip_destroy(None) == 0
+
+
+def test_fails_loudly_without_a_gpu(mh):
+    if mh.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(mh.MurbHipError) as e:
+        mh.Simulation(1000)
+    assert e.value.code == -2002     # MURBHIP_E_NO_DEVICE: no CPU fallback exists
+
+
+@pytest.mark.parametrize("scheme,n", [("random", 2048), ("random", 2049), ("galaxy", 2048), ("galaxy", 2049)])
+def test_product_initial_conditions_bit_exact(mh, scheme, n):
+    g = np.load(os.path.join(GOLDEN, f"ref_{scheme}_{n}.npz"))
+    assert mh.host_padding(n, scheme) == int(g["padding"][0])
+    s = mh.init_bodies(n, scheme, with_padding=True)
+    for k in mh.FIELDS:
+        assert np.array_equal(bits(s[k]), bits(g["init_" + k])), k
+
+
+def test_product_initial_conditions_benchmark_size(mh):
+    g = np.load(os.path.join(GOLDEN, "ref_galaxy_30000_summary.npz"))
+    s = mh.init_bodies(30000, "galaxy")
+    for k in mh.FIELDS:
+        a = s[k]
+        got = np.array([a.astype(np.float64).sum(), (a.astype(np.float64) ** 2).sum(),
+                        float(np.bitwise_xor.reduce(bits(a)))])
+        assert np.array_equal(got, g["init_sum_" + k]), k
+    # first bodies quoted in SURVEY.md §8c
+    assert s["m"][0] == np.float32(2e24) and s["m"][1] == np.float32(4.20093873e20)
+    assert s["qy"][1] == np.float32(117566928.0)
+
+
+@pytest.mark.parametrize("scheme", ["random", "galaxy"])
+def test_product_host_integrator_bit_exact(mh, scheme):
+    n = 4000
+    g = np.load(os.path.join(GOLDEN, f"ref_integrator_{scheme}_{n}.npz"))
+    acc = (np.arange(1, n + 1, dtype=np.float32), np.full(n, 3.0, np.float32), (n - np.arange(n)).astype(np.float32))
+    for steps in (1, 4):
+        out = mh.host_integrate(n, scheme, acc, np.float32(0.01), steps)
+        for k in mh.FIELDS[:6]:
+            assert np.array_equal(bits(out[k]), bits(g[f"steps{steps}_{k}"])), k
+
+
+def test_driver_cli_contract():
+    """murb-hip mirrors the reference CLI (main.cpp:61-165): missing -n/-i -> usage + exit(-1);
+    unknown --im tag -> message + exit(-1); --soft 0 rejected."""
+    exe = os.path.join(ROOT, "nbody-eurohpc_amd", "bin", "murb-hip")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 255 and "Usage" in r.stdout
+    r = subprocess.run([exe, "-n", "100", "-i", "1", "--im", "cpu+nope"], capture_output=True, text=True)
+    assert r.returncode == 255 and "Implementation 'cpu+nope' does not exist... Exiting." in r.stdout
+    r = subprocess.run([exe, "-n", "100", "-i", "1", "--soft", "0"], capture_output=True, text=True)
+    assert r.returncode == 255 and "Softening factor can't be equal to 0" in r.stdout

@@ -1,0 +1,108 @@
+"""CPU: the oracle (oracle/murb_oracle.cpp, oracle_optim.cpp) against the committed fixtures that were
+produced by the real reference (tests/golden/make_golden.py).  This is what pins the oracle on a machine
+without /root/reference (the GPU box).  Bit-exact for initial conditions, cpu+optim and the integrator;
+cpu+naive (pow-based) to 1e-5."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+SOFT, DT = np.float32(2e8), np.float32(3600.0)
+DYN = ("qx", "qy", "qz", "vx", "vy", "vz")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("scheme,n", [("random", 2048), ("random", 2049), ("galaxy", 2048), ("galaxy", 2049)])
+def test_small_cases_bit_exact(O, scheme, n):
+    g = np.load(os.path.join(GOLDEN, f"ref_{scheme}_{n}.npz"))
+    assert O.padding(n) == int(g["padding"][0])
+    init = O.init_bodies(n, scheme, with_padding=True)
+    for k in O.FIELDS:
+        assert np.array_equal(bits(init[k]), bits(g["init_" + k])), k
+    s = {k: v[:n].copy() for k, v in init.items()}
+    acc = O.simulate(s, 1, "cpu+optim", SOFT, DT)
+    for c, a in zip("xyz", acc):
+        assert np.array_equal(bits(a), bits(g["optim_acc1_a" + c]))
+    for k in DYN:
+        assert np.array_equal(bits(s[k]), bits(g["optim_step1_" + k]))
+    iters = int(g["iters"][0])
+    if iters > 1:
+        O.simulate(s, iters - 1, "cpu+optim", SOFT, DT)
+    for k in DYN:
+        assert np.array_equal(bits(s[k]), bits(g["optim_final_" + k]))
+    s = {k: v[:n].copy() for k, v in init.items()}
+    O.simulate(s, iters, "cpu+naive", SOFT, DT)
+    for k in ("qx", "qy", "qz"):
+        np.testing.assert_allclose(s[k], g["naive_final_" + k], rtol=1e-5)
+    # the reference's count of work and bytes (SimulationNBodyOptim.cpp:11, Interface.cpp:15-16)
+    assert float(g["flops_per_ite"][0]) == np.float32(20.0) * np.float32(n) * np.float32(n)
+    assert float(g["allocated_bytes"][0]) == (n + O.padding(n)) * 4 * (16 + 3)
+
+
+@pytest.mark.parametrize("scheme", ["random", "galaxy"])
+def test_integrator_bit_exact(O, scheme):
+    n = 4000
+    g = np.load(os.path.join(GOLDEN, f"ref_integrator_{scheme}_{n}.npz"))
+    acc = (np.arange(1, n + 1, dtype=np.float32), np.full(n, 3.0, np.float32), (n - np.arange(n)).astype(np.float32))
+    s = O.init_bodies(n, scheme)
+    for step in range(1, 5):
+        O.integrate(s, acc, np.float32(0.01))
+        if step in (1, 4):
+            for k in DYN:
+                assert np.array_equal(bits(s[k]), bits(g[f"steps{step}_{k}"]))
+
+
+def test_benchmark_config_summary(O):
+    """N = 30000 galaxy: initial state, 1 and 5 cpu+optim iterations against checksums + samples."""
+    g = np.load(os.path.join(GOLDEN, "ref_galaxy_30000_summary.npz"))
+    n = 30000
+    s = O.init_bodies(n, "galaxy")
+    edge, sub = g["edge"], g["sub"]
+
+    def sums(a):
+        return np.array([a.astype(np.float64).sum(), (a.astype(np.float64) ** 2).sum(),
+                         float(np.bitwise_xor.reduce(bits(a)))])
+    for k in O.FIELDS:
+        assert np.array_equal(sums(s[k]), g["init_sum_" + k]), k
+        assert np.array_equal(bits(s[k][edge]), bits(g["init_edge_" + k]))
+    f64 = O.accel_f64_subset(s, sub, SOFT)
+    for c, a in zip("xyz", f64):
+        np.testing.assert_allclose(a, g["f64_acc1_sub_a" + c], rtol=1e-12)
+    acc = O.simulate(s, 1, "cpu+optim", SOFT, DT)
+    for c, a in zip("xyz", acc):
+        assert np.array_equal(bits(a[sub]), bits(g["optim_acc1_sub_a" + c]))
+        assert np.array_equal(sums(a), g["optim_acc1_sum_a" + c])
+    for k in DYN:
+        assert np.array_equal(sums(s[k]), g[f"optim_step1_sum_{k}"])
+    # the oracle's own distance from the fp64 truth: SURVEY.md §8c quotes 1.2e-5 max / 3e-6 rms here
+    e = O.rel_err([a[sub] for a in acc], f64)
+    assert e.max() < 2e-5 and np.sqrt((e ** 2).mean()) < 5e-6
+
+
+def test_known_answer_facts(O):
+    """self term is 0, massless bodies exert nothing, momentum balance."""
+    s = O.init_bodies(1, "random")
+    assert all(float(a[0]) == 0.0 for a in O.accel_optim(s, SOFT))
+    ax, ay, az = O.accel_f64(s, SOFT)
+    assert ax[0] == 0 and ay[0] == 0 and az[0] == 0
+    s = O.init_bodies(512, "galaxy")
+    a = O.accel_f64(s, SOFT)
+    m = s["m"].astype(np.float64)
+    for c in a:
+        assert abs((m * c).sum()) <= 1e-12 * (m * np.abs(c)).sum()
+    s2 = {k: np.concatenate([v, v[:5]]) for k, v in s.items()}
+    s2["m"][512:] = 0
+    a2 = O.accel_f64(s2, SOFT)
+    for c, c2 in zip(a, a2):
+        np.testing.assert_array_equal(c, c2[:512])
+    # slice evaluation used by the multi-rank tests equals the whole
+    whole = O.accel_slice_f32(s, 0, 512, SOFT)
+    parts = [O.accel_slice_f32(s, 0, 200, SOFT), O.accel_slice_f32(s, 200, 512, SOFT)]
+    for w, p0, p1 in zip(whole, parts[0], parts[1]):
+        assert np.array_equal(bits(w), bits(np.concatenate([p0, p1])))
+    assert O.rel_err(whole, a).max() < 2e-6
