@@ -139,6 +139,8 @@ int murbhip_sync(murbhip_ctx* ctx);
  *   "jsplit"         number of j-chunks a body's sum is split into (0 = auto)
  *   "profile"        1: bracket every force kernel with HIP events (read with murbhip_get_info)
  *   "overlap"        sharded/rank mode: 1 (default) own-slice tiles first, exchange on the 2nd stream
+ *   "force_exchange" 1: run the position exchange even with a single rank/shard (self-test of the
+ *                    RCCL binding on a one-GPU machine; rank mode needs a unique id at creation)
  */
 int murbhip_set_option(murbhip_ctx* ctx, const char* key, long value);
 

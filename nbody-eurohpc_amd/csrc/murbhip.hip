@@ -136,6 +136,7 @@ struct murbhip_ctx {
     bool gather_pending = false;   // an exchange into rec[cur] is in flight on the comm streams
     // options
     int variant = 0, jsplit = 0, profile = 0, overlap = 1;
+    int force_exchange = 0;   // run the exchange even with one rank (self-test of the RCCL binding)
     // facts
     int cu_count = 0, clock_mhz = 0;
     int last_parts = 0;
@@ -342,6 +343,7 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
         if (c->world == 1) {
+            if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
             RC_TRY(enqueue_force(c, sh, p, 0));
         } else if (c->overlap) {
             RC_TRY(enqueue_force(c, sh, p, 0));   // own slice: written by our own integrate, already ordered
@@ -355,7 +357,7 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
         RC_TRY(enqueue_integrate(c, sh, p.parts_local + p.parts_remote, dt, update_state));
     }
     if (update_state) {
-        if (c->world > 1) RC_TRY(enqueue_exchange(c, c->cur ^ 1));
+        if (c->world > 1 || c->force_exchange) RC_TRY(enqueue_exchange(c, c->cur ^ 1));
         c->cur ^= 1;
     }
     return 0;
@@ -548,9 +550,9 @@ int murbhip_create_rank(murbhip_ctx** out, unsigned long n, float soft, float g,
 {
     if (world < 1 || rank < 0 || rank >= world || (unsigned long)world > n) return MURBHIP_E_INVALID;
     if (world > 1 && !unique_id) return MURBHIP_E_INVALID;
-    if (world > 1 && !rccl().ok) return MURBHIP_E_NO_RCCL;
+    if ((world > 1 || unique_id) && !rccl().ok) return MURBHIP_E_NO_RCCL;
     RC_TRY(create_common(out, n, soft, g, world, 1, &device, &rank, 1, true));
-    if (world > 1) {
+    if (world > 1 || unique_id) {   // a one-rank communicator is legal and exercises the whole RCCL binding
         rccl_id_t id;
         std::memcpy(&id, unique_id, sizeof id);
         hipSetDevice(device);
@@ -729,6 +731,10 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     if (k == "variant") { if (value < 0 || value > kNumVariants) return MURBHIP_E_INVALID; c->variant = (int)value; }
     else if (k == "jsplit") { if (value < 0 || value > kMaxParts / 2) return MURBHIP_E_INVALID; c->jsplit = (int)value; }
     else if (k == "overlap") c->overlap = value ? 1 : 0;
+    else if (k == "force_exchange") {
+        if (value && c->exchange == 1 && !c->shards[0].comm_rccl) return MURBHIP_E_STATE;
+        c->force_exchange = value ? 1 : 0;
+    }
     else if (k == "profile") {
         c->profile = value ? 1 : 0;
         for (Shard& sh : c->shards) {

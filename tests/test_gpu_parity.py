@@ -229,6 +229,23 @@ def test_rank_mode_single_rank(gpu, O):
             assert np.array_equal(bits(v), bits(r0.state()[k]))
 
 
+def test_rccl_binding_single_rank(gpu, O):
+    """dlopen'd RCCL end to end on one GPU: unique id, a 1-rank communicator, in-place all-gather of the
+    rank's slice every step on the second stream — results identical to the plain single-GPU run."""
+    n = 3000
+    s = O.init_bodies(n, "galaxy")
+    uid = gpu.unique_id()
+    assert len(uid) == 128 and any(uid)
+    with gpu.Simulation(n, soft=SOFT) as one, gpu.Simulation(n, soft=SOFT, rank=0, world=1, uid=uid) as r0:
+        r0.set_option("force_exchange", 1)
+        one.upload(s); r0.upload(s)
+        one.steps(DT, 5); r0.steps(DT, 5)
+        one.sync(); r0.sync()
+        a, b = one.state(), r0.state()
+        for k in a:
+            assert np.array_equal(bits(a[k]), bits(b[k])), k
+
+
 def test_errors_are_reported(gpu):
     with gpu.Simulation(100, soft=SOFT) as sim:
         with pytest.raises(gpu.MurbHipError):
