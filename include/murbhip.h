@@ -136,7 +136,8 @@ int murbhip_sync(murbhip_ctx* ctx);
 
 /* Integer options.  Keys:
  *   "variant"        force kernel variant (0 = library default)
- *   "jsplit"         number of j-chunks a body's sum is split into (0 = auto)
+ *   "jsplit"         2-D grid variants: number of j-chunks a body's sum is split into; persistent
+ *                    variant: scheduling rounds (workgroups per resident slot).  0 = auto
  *   "profile"        1: bracket every force kernel with HIP events (read with murbhip_get_info)
  *   "overlap"        sharded/rank mode: 1 (default) own-slice tiles first, exchange on the 2nd stream
  *   "force_exchange" 1: run the position exchange even with a single rank/shard (self-test of the
@@ -145,7 +146,7 @@ int murbhip_sync(murbhip_ctx* ctx);
 int murbhip_set_option(murbhip_ctx* ctx, const char* key, long value);
 
 /* Numeric facts.  Keys: "cu_count", "clock_mhz", "n", "slots", "world", "rank", "jsplit", "variant",
- * "force_launches", "force_ms_avg", "force_ms_total", "interactions_per_launch",
+ * "workgroups", "force_launches", "force_ms_avg", "force_ms_total", "interactions_per_launch",
  * "device_bytes". */
 int murbhip_get_info(murbhip_ctx* ctx, const char* key, double* value);
 

@@ -217,6 +217,116 @@ __global__ __launch_bounds__(WAVES * 64) void murb_force_kernel(const MurbForceA
     }
 }
 
+// ---- balanced persistent schedule -----------------------------------------------------------------
+// The (i group, j tile) units of a launch, linearised group-major (u = g * tiles + t), are cut into
+// `nblocks` contiguous, equally long runs: workgroup b owns [begin(b), begin(b+1)).  Every workgroup
+// does the same amount of work whatever N is (the 2-D grid above leaves the last scheduling round
+// partly empty: N = 30 000 gives 938 i groups for 1024 SIMDs).  A group whose tiles are split over
+// several workgroups gets one partial-sum row per workgroup: row = b - block_of(first unit of g).
+struct MurbSchedule {
+    int groups, tiles, nblocks, row_base;
+};
+
+__host__ __device__ __forceinline__ long murb_sched_begin(const MurbSchedule& s, long b)
+{
+    return ((long)s.groups * (long)s.tiles * b) / (long)s.nblocks;
+}
+
+__host__ __device__ __forceinline__ int murb_sched_block_of(const MurbSchedule& s, long u)
+{
+    const long total = (long)s.groups * (long)s.tiles;
+    long b = (u * (long)s.nblocks) / total;
+    while (b + 1 < s.nblocks && murb_sched_begin(s, b + 1) <= u) ++b;
+    while (b > 0 && murb_sched_begin(s, b) > u) --b;
+    return (int)b;
+}
+
+// rows a group's partial sums occupy (>= 1)
+__host__ __device__ __forceinline__ int murb_sched_rows_of_group(const MurbSchedule& s, int g)
+{
+    return murb_sched_block_of(s, (long)(g + 1) * s.tiles - 1) - murb_sched_block_of(s, (long)g * s.tiles) + 1;
+}
+
+template <int R, int WAVES, int STAGE>
+__global__ __launch_bounds__(WAVES * 64) void murb_force_persistent(const MurbForceArgs a, const MurbSchedule s)
+{
+    static_assert(R % 2 == 0 && MURB_TILE_BODIES % (WAVES * R) == 0, "i groups must tile the layout");
+    __shared__ float4 lds[STAGE * MURB_TILE_F4];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float soft2 = a.soft2;
+    long u = murb_sched_begin(s, blockIdx.x);
+    const long u_end = murb_sched_begin(s, blockIdx.x + 1);
+
+    while (u < u_end) {
+        const int g = (int)(u / s.tiles);
+        const int t0 = (int)(u - (long)g * s.tiles);
+        const int run = (int)((u_end - u) < (long)(s.tiles - t0) ? (u_end - u) : (long)(s.tiles - t0));
+        const int i_slot = a.i_first_slot + (g * WAVES + wave) * R;   // wave-uniform
+
+        float xi[R], yi[R], zi[R];
+        {
+            const unsigned long ra = murb_rec_a((unsigned long)(i_slot >> 1));
+#pragma unroll
+            for (int h = 0; h < R / 2; ++h) {
+                const float4 A = a.rec[ra + h];
+                const float4 B = a.rec[ra + h + MURB_TILE_PAIRS];
+                xi[2 * h] = A.x; xi[2 * h + 1] = A.y;
+                yi[2 * h] = A.z; yi[2 * h + 1] = A.w;
+                zi[2 * h] = B.x; zi[2 * h + 1] = B.y;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                xi[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xi[r])));
+                yi[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, yi[r])));
+                zi[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, zi[r])));
+            }
+        }
+        murb_f2 ax[R], ay[R], az[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { ax[r] = (murb_f2)(0.f); ay[r] = (murb_f2)(0.f); az[r] = (murb_f2)(0.f); }
+
+        for (int vs = t0; vs < t0 + run; vs += STAGE) {
+            const int nt = (t0 + run - vs) < STAGE ? (t0 + run - vs) : STAGE;
+            __syncthreads();   // previous stage fully consumed
+            for (int t = 0; t < nt; ++t) {
+                const float4* src = a.rec + (unsigned long)murb_actual_tile(a.tiles, vs + t) * MURB_TILE_F4;
+#pragma unroll
+                for (int k = threadIdx.x; k < MURB_TILE_F4; k += WAVES * 64) lds[t * MURB_TILE_F4 + k] = src[k];
+            }
+            __syncthreads();
+            for (int t = 0; t < nt; ++t) {
+                const float4* tile = lds + t * MURB_TILE_F4;
+#pragma unroll
+                for (int q = 0; q < MURB_TILE_PAIRS; q += 64) {
+                    const float4 A = tile[q + lane];
+                    const float4 B = tile[q + lane + MURB_TILE_PAIRS];
+                    const murb_f2 xj = {A.x, A.y}, yj = {A.z, A.w}, zj = {B.x, B.y}, gj = {B.z, B.w};
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        murb_interact_pk(xj, yj, zj, gj, xi[r], yi[r], zi[r], soft2, ax[r], ay[r], az[r]);
+                }
+            }
+        }
+
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float sx = murb_wave_sum(ax[r].x + ax[r].y);
+            const float sy = murb_wave_sum(ay[r].x + ay[r].y);
+            const float sz = murb_wave_sum(az[r].x + az[r].y);
+            if (lane == r) { ox = sx; oy = sy; oz = sz; }
+        }
+        if (lane < R) {
+            const int row = s.row_base + (int)blockIdx.x - murb_sched_block_of(s, (long)g * s.tiles);
+            a.accp[(unsigned long)row * a.acc_stride + (unsigned long)(i_slot - a.i_first_slot) + lane] =
+                make_float4(ox, oy, oz, 0.f);
+        }
+        u += run;
+    }
+}
+
 // ---- integrate ------------------------------------------------------------------------------------
 // Reference semantics, Bodies.cpp:260-278 (= CUDABodies.cu:126-153):
 //     aDt = a*dt (fp32);  q' = q + (v + aDt*0.5)*dt with the parenthesis and the add evaluated in
@@ -229,10 +339,13 @@ struct MurbIntegrateArgs {
     float* acc_out;          // ax | ay | az, acc_stride entries each (sum of the partials)
     int i_first_slot;        // first slot of the local slice
     int count;               // real bodies in the local slice
-    int nparts;
+    int nparts;              // rows to add when nsched == 0
     unsigned int acc_stride;
     float dt;
     int update_state;        // 0: only reduce partial sums into acc_out
+    int nsched;              // persistent launches that produced accp (0, 1 or 2)
+    int group_bodies;        // bodies per i group of those launches
+    MurbSchedule sched[2];
 };
 
 // `#pragma clang fp contract(off)`: hipcc contracts a*b+c into one FMA by default (also through the
@@ -267,11 +380,25 @@ __global__ __launch_bounds__(256) void murb_integrate_kernel(const MurbIntegrate
     if (s0 >= (int)a.acc_stride) return;
 
     float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-    for (int p = 0; p < a.nparts; ++p) {
-        const float4 u = a.accp[(unsigned long)p * a.acc_stride + s0];
-        const float4 w = a.accp[(unsigned long)p * a.acc_stride + s0 + 1];
-        acc0.x += u.x; acc0.y += u.y; acc0.z += u.z;
-        acc1.x += w.x; acc1.y += w.y; acc1.z += w.z;
+    if (a.nsched == 0) {
+        for (int p = 0; p < a.nparts; ++p) {
+            const float4 u = a.accp[(unsigned long)p * a.acc_stride + s0];
+            const float4 w = a.accp[(unsigned long)p * a.acc_stride + s0 + 1];
+            acc0.x += u.x; acc0.y += u.y; acc0.z += u.z;
+            acc1.x += w.x; acc1.y += w.y; acc1.z += w.z;
+        }
+    } else {
+        const int g = s0 / a.group_bodies;   // both slots of a pair are in the same group
+        for (int k = 0; k < a.nsched; ++k) {
+            if (g >= a.sched[k].groups) continue;
+            const int rows = murb_sched_rows_of_group(a.sched[k], g);
+            for (int p = a.sched[k].row_base; p < a.sched[k].row_base + rows; ++p) {
+                const float4 u = a.accp[(unsigned long)p * a.acc_stride + s0];
+                const float4 w = a.accp[(unsigned long)p * a.acc_stride + s0 + 1];
+                acc0.x += u.x; acc0.y += u.y; acc0.z += u.z;
+                acc1.x += w.x; acc1.y += w.y; acc1.z += w.z;
+            }
+        }
     }
     a.acc_out[s0] = acc0.x; a.acc_out[s0 + 1] = acc1.x;
     a.acc_out[a.acc_stride + s0] = acc0.y; a.acc_out[a.acc_stride + s0 + 1] = acc1.y;

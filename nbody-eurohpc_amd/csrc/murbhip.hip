@@ -148,8 +148,9 @@ namespace {
 
 struct Plan {
     int variant;   // resolved
-    int R, waves;
-    int parts_local, parts_remote;   // j chunks for the own-slice launch and the rest
+    int parts_local, parts_remote;   // 2-D grid variants: j chunks of the own-slice launch and of the rest
+    bool persistent;                 // balanced persistent schedule (murb_force_persistent)
+    MurbSchedule sched[2];           // [0] own slice (or everything), [1] the rest
 };
 
 template <int MODE, int R, int WAVES, int STAGE>
@@ -173,12 +174,50 @@ int launch_force(int variant, const MurbForceArgs& a, int i_slots, hipStream_t s
         default: return MURBHIP_E_INVALID;
     }
 }
-constexpr int kNumVariants = 6;
-constexpr int kDefaultVariant = 1;
+constexpr int kNumVariants = 7;
+constexpr int kDefaultVariant = 1;   // the persistent schedule (7) measured no faster: DESIGN.md §4.1
+constexpr int kPersistentVariant = 7;   // murb_force_persistent<8, 4, 4>
+constexpr int kRowsPerLaunch = kMaxParts / 2;
+
+int launch_persistent(const MurbForceArgs& a, const MurbSchedule& sc, hipStream_t s)
+{
+    hipLaunchKernelGGL((murb_force_persistent<8, 4, 4>), dim3((unsigned)sc.nblocks), dim3(256), 0, s, a, sc);
+    return hip_rc(hipGetLastError());
+}
+
+// Workgroups of the persistent kernel that fit on the chip at once.
+int resident_blocks(const murbhip_ctx* c)
+{
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, murb_force_persistent<8, 4, 4>, 256, 0) != hipSuccess || n < 1)
+            n = 4;
+        per_cu = n;
+    }
+    return per_cu * std::max(c->cu_count, 1);
+}
+
+// Cut groups x tiles units into equal runs: `rounds` runs per resident slot (so that a slot lost to
+// another process or to the profiler costs 1/rounds, not 2x), at least ~8 tiles per run (the
+// end-of-run reduction is ~1 % of that), and few enough runs that a group spans < kRowsPerLaunch rows.
+MurbSchedule make_schedule(const murbhip_ctx* c, long groups, long tiles, int row_base)
+{
+    MurbSchedule sc{(int)groups, (int)tiles, 1, row_base};
+    const long units = groups * tiles;
+    if (units <= 0) { sc.nblocks = 0; return sc; }
+    const long slots = resident_blocks(c);
+    long rounds = c->jsplit > 0 ? c->jsplit : std::min<long>(8, std::max<long>(1, units / (slots * 8)));
+    long nb = std::min(units, slots * rounds);
+    nb = std::min(nb, std::max<long>(1, (kRowsPerLaunch - 2) * groups));
+    sc.nblocks = (int)std::max<long>(nb, 1);
+    return sc;
+}
 
 int variant_group(int variant)   // bodies per workgroup = waves * R
 {
     switch (variant) {
+        case kPersistentVariant: return 32;
         case 2: case 6: return 16;
         case 5: return 64;
         default: return 32;
@@ -204,6 +243,17 @@ Plan make_plan(const murbhip_ctx* c)
     p.variant = (c->variant >= 1 && c->variant <= kNumVariants) ? c->variant : kDefaultVariant;
     const unsigned long tiles_local = c->slice / MURB_TILE_BODIES;
     const unsigned long tiles_remote = (c->slots - c->slice) / MURB_TILE_BODIES;
+    p.persistent = p.variant == kPersistentVariant;
+    if (p.persistent) {
+        // every shard sweeps the same number of i groups: the largest slice count decides
+        unsigned long first, count;
+        partition(c->n, c->world, 0, &first, &count);
+        const long groups = (long)((count + 31) / 32);
+        p.sched[0] = make_schedule(c, groups, (long)tiles_local, 0);
+        p.sched[1] = make_schedule(c, groups, (long)tiles_remote, kRowsPerLaunch);
+        p.parts_local = p.parts_remote = 0;
+        return p;
+    }
     if (c->world == 1) {
         p.parts_local = c->jsplit > 0 ? std::min<int>(c->jsplit, (int)std::min<unsigned long>(tiles_local, kMaxParts))
                                       : auto_parts(c, p.variant, c->slice, tiles_local);
@@ -256,18 +306,32 @@ int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
         a.chunk_first = p.parts_local;
         a.nchunks = p.parts_remote;
     }
-    if (a.nchunks <= 0 || a.tiles.count <= 0) return 0;
     const int i_slots = (int)sh.count;   // the grid rounds up to whole i groups; the extra slots hold mass 0
-    RC_TRY(prof_begin(c, sh));
-    RC_TRY(launch_force(p.variant, a, i_slots, sh.compute));
-    RC_TRY(prof_end(c, sh));
+    if (p.persistent) {
+        const MurbSchedule& sc = p.sched[which];
+        if (sc.nblocks <= 0 || a.tiles.count <= 0) return 0;
+        RC_TRY(prof_begin(c, sh));
+        RC_TRY(launch_persistent(a, sc, sh.compute));
+        RC_TRY(prof_end(c, sh));
+    } else {
+        if (a.nchunks <= 0 || a.tiles.count <= 0) return 0;
+        RC_TRY(prof_begin(c, sh));
+        RC_TRY(launch_force(p.variant, a, i_slots, sh.compute));
+        RC_TRY(prof_end(c, sh));
+    }
     c->interactions_per_launch = (double)i_slots * (double)a.tiles.count * MURB_TILE_BODIES;
     return 0;
 }
 
-int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int update_state)
+int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int update_state, const Plan* plan = nullptr)
 {
     MurbIntegrateArgs a{};
+    if (plan && plan->persistent) {
+        a.group_bodies = 32;
+        a.sched[0] = plan->sched[0];
+        a.nsched = 1;
+        if (c->world > 1 && plan->sched[1].nblocks > 0) { a.sched[1] = plan->sched[1]; a.nsched = 2; }
+    }
     a.rec_in = sh.rec[c->cur];
     a.rec_out = sh.rec[c->cur ^ 1];
     a.vel = sh.vel;
@@ -354,7 +418,7 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
             RC_TRY(enqueue_force(c, sh, p, 0));
             RC_TRY(enqueue_force(c, sh, p, 1));
         }
-        RC_TRY(enqueue_integrate(c, sh, p.parts_local + p.parts_remote, dt, update_state));
+        RC_TRY(enqueue_integrate(c, sh, p.parts_local + p.parts_remote, dt, update_state, &p));
     }
     if (update_state) {
         if (c->world > 1 || c->force_exchange) RC_TRY(enqueue_exchange(c, c->cur ^ 1));
@@ -760,7 +824,9 @@ int murbhip_get_info(murbhip_ctx* c, const char* key, double* value)
     else if (k == "slots") *value = (double)c->slots;
     else if (k == "world") *value = c->world;
     else if (k == "rank") *value = c->shards[0].rank;
-    else if (k == "jsplit") *value = p.parts_local + p.parts_remote;
+    else if (k == "jsplit") *value = p.persistent ? (double)p.sched[0].nblocks / std::max(resident_blocks(c), 1)
+                                                  : (double)(p.parts_local + p.parts_remote);
+    else if (k == "workgroups") *value = p.persistent ? p.sched[0].nblocks + (c->world > 1 ? p.sched[1].nblocks : 0) : 0;
     else if (k == "variant") *value = p.variant;
     else if (k == "interactions_per_launch") *value = c->interactions_per_launch;
     else if (k == "device_bytes") { double b = 0; for (Shard& sh : c->shards) b += (double)sh.bytes; *value = b; }
