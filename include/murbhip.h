@@ -56,7 +56,7 @@ const char* murbhip_error_string(int code);
 int murbhip_partition(unsigned long n, int world, int rank, unsigned long* first, unsigned long* count);
 
 /* Device slots each rank owns in the replicated position buffer: the largest slice rounded up to
- * the layout tile (a multiple of 512 bodies).  Slots past a rank's count hold mass 0 and contribute
+ * the slice unit (a multiple of 1024 body slots).  Slots past a rank's count hold mass 0 and contribute
  * exactly 0 to every sum, so one equal-count all-gather replaces the reference's MPI_Allgatherv
  * (SimulationNBodyMultiNode.cpp:104-114). */
 unsigned long murbhip_slice_slots(unsigned long n, int world);
@@ -135,7 +135,8 @@ int murbhip_sync(murbhip_ctx* ctx);
 /* ------------------------------------------------------------------ tuning and measurement */
 
 /* Integer options.  Keys:
- *   "variant"        force kernel variant (0 = library default)
+ *   "variant"        force kernel variant (0 = auto: pair-symmetric kernel (8) on one GPU
+ *                    from 28 672 bodies up, one-sided kernel (1) otherwise)
  *   "jsplit"         2-D grid variants: number of j-chunks a body's sum is split into; persistent
  *                    variant: scheduling rounds (workgroups per resident slot).  0 = auto
  *   "profile"        1: bracket every force kernel with HIP events (read with murbhip_get_info)

@@ -343,6 +343,8 @@ struct MurbIntegrateArgs {
     unsigned int acc_stride;
     float dt;
     int update_state;        // 0: only reduce partial sums into acc_out
+    const float* sym_part;   // pair-symmetric kernel: 3 planes [c][sym_nrows][acc_stride]; null otherwise
+    int sym_rows, sym_nrows; // rows to add / rows per plane
     int nsched;              // persistent launches that produced accp (0, 1 or 2)
     int group_bodies;        // bodies per i group of those launches
     MurbSchedule sched[2];
@@ -380,7 +382,20 @@ __global__ __launch_bounds__(256) void murb_integrate_kernel(const MurbIntegrate
     if (s0 >= (int)a.acc_stride) return;
 
     float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-    if (a.nsched == 0) {
+    if (a.sym_part) {
+        // one partial row per block of the symmetric decomposition, added in row order
+        const float* px = a.sym_part + s0;
+        const float* py = px + (unsigned long)a.sym_nrows * a.acc_stride;
+        const float* pz = py + (unsigned long)a.sym_nrows * a.acc_stride;
+        for (int r = 0; r < a.sym_rows; ++r) {
+            const float2 u = *reinterpret_cast<const float2*>(px + (unsigned long)r * a.acc_stride);
+            const float2 v = *reinterpret_cast<const float2*>(py + (unsigned long)r * a.acc_stride);
+            const float2 w = *reinterpret_cast<const float2*>(pz + (unsigned long)r * a.acc_stride);
+            acc0.x += u.x; acc1.x += u.y;
+            acc0.y += v.x; acc1.y += v.y;
+            acc0.z += w.x; acc1.z += w.y;
+        }
+    } else if (a.nsched == 0) {
         for (int p = 0; p < a.nparts; ++p) {
             const float4 u = a.accp[(unsigned long)p * a.acc_stride + s0];
             const float4 w = a.accp[(unsigned long)p * a.acc_stride + s0 + 1];

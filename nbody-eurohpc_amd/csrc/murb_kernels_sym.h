@@ -1,0 +1,280 @@
+// Pair-symmetric force kernel: every unordered body pair is evaluated ONCE and applied to both
+// bodies (Newton's third law) — the idea of the reference's cpu+optim loop
+// (reference SimulationNBodyOptim.cpp:60-82: `a_i += s*m_j*d ; a_j -= s*m_i*d`), mapped to gfx950.
+//
+// Why: the one-sided kernel (murb_kernels.h) keeps the vector ALUs 97 % busy; the only way up is
+// fewer instructions.  One-sided: 12 packed + 2 rsq wave instructions per (i, j-pair) = 2
+// interactions.  Symmetric: 16 packed + 2 rsq per (i, j-pair) = 4 interactions (both directions):
+// 20.6 instead of 32.9 issue cycles per interaction.
+//
+// Decomposition: bodies are cut into blocks of MURB_SYM_BLOCK = 1024 slots (2 layout tiles).  A
+// workgroup takes one block pair (I <= J):
+//   * the J block (512 pairs) is staged in LDS once; lane l of every wave owns j-pairs l, l+64, ...
+//     (8 per lane) and keeps their 24 packed accumulators in VGPRs for the whole item;
+//   * the 4 waves split the I block: a wave walks its 64 i groups of R = 4 bodies (coordinates and
+//     G*m in SGPRs), 8 fully unrolled steps per group;
+//   * after a group the 12 i-side sums (4 bodies x 3) are spread over 64 lanes x 2 halves; they are
+//     folded with a transposing reduction (v_permlane32_swap / v_permlane16_swap, then DPP row
+//     mirrors with a select): 39 instructions instead of 12 x 11, and written to partial row J;
+//   * at the end the four waves' j-side sums are combined through LDS in a fixed order and written
+//     to partial row I.  Diagonal items (I == J) evaluate the full square and only keep the i side.
+// Every (row r, block K) cell of the partial-sum planes is written exactly once per launch (by item
+// (min(r,K), max(r,K))), so nothing needs zeroing and the row sum in the integrate kernel is
+// bit-reproducible.
+#ifndef MURB_KERNELS_SYM_H_
+#define MURB_KERNELS_SYM_H_
+
+#include "murb_kernels.h"
+
+#define MURB_SYM_BLOCK 1024                       /* body slots per block             */
+#define MURB_SYM_PAIRS (MURB_SYM_BLOCK / 2)       /* 512 pairs                        */
+#define MURB_SYM_STEPS (MURB_SYM_PAIRS / 64)      /* 8 pair-vectors per lane          */
+#define MURB_SYM_R 4                              /* i bodies per group               */
+
+struct MurbSymArgs {
+    const float4* rec;     // body records (murb_layout.h)
+    float* part;           // partial sums, 3 planes: part[(c * nrows + row) * row_stride + local_slot]
+    int first_block;       // block index (in the record buffer) of local block 0
+    int nblocks;           // T: blocks of the (local) square being evaluated
+    int nrows;             // rows per plane (>= T)
+    unsigned int row_stride;   // floats per row (= local slots)
+    float soft2;
+};
+
+__device__ __forceinline__ void murb_swap32(float& a, float& b)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void murb_swap16(float& a, float& b)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+template <int CTRL> __device__ __forceinline__ float murb_dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// Transposing wave reduction of 12 values.  On return lane L holds the 64-lane total of value
+//   idx(L) = (L & 4) ? 8 + 2*b4 + b5 : 4*b3 + 2*b4 + b5      (b3 = bit 3 of L, ...)
+// (lanes of one quad hold the same total).
+__device__ __forceinline__ float murb_reduce12(float (&v)[12], int lane)
+{
+    // distance 32 and 16: swap halves / rows between two registers, then one add folds both
+    float w[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { murb_swap32(v[2 * k], v[2 * k + 1]); w[k] = v[2 * k] + v[2 * k + 1]; }
+    float x[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { murb_swap16(w[2 * m], w[2 * m + 1]); x[m] = w[2 * m] + w[2 * m + 1]; }
+    // distance 8 (row mirror): lanes with bit 3 clear keep x0, the others x1; x2 is folded on all lanes
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+    const float keep3 = b3 ? x[1] : x[0], send3 = b3 ? x[0] : x[1];
+    const float y0 = keep3 + murb_dpp<0x140>(send3);          // row_mirror
+    const float y1 = x[2] + murb_dpp<0x140>(x[2]);
+    // distance 4 (half-row mirror): bit 2 clear keeps y0, set keeps y1
+    const float keep2 = b2 ? y1 : y0, send2 = b2 ? y0 : y1;
+    float z = keep2 + murb_dpp<0x141>(send2);                 // row_half_mirror
+    z += murb_dpp<0x4E>(z);                                   // quad_perm [2,3,0,1]
+    z += murb_dpp<0xB1>(z);                                   // quad_perm [1,0,3,2]
+    return z;
+}
+
+// one i body against a j pair, both directions
+__device__ __forceinline__ void murb_interact_sym(const murb_f2 xj, const murb_f2 yj, const murb_f2 zj, const murb_f2 gj,
+                                                  const float xi, const float yi, const float zi, const float gi,
+                                                  const float soft2, murb_f2& aix, murb_f2& aiy, murb_f2& aiz,
+                                                  murb_f2& ajx, murb_f2& ajy, murb_f2& ajz)
+{
+    const murb_f2 dx = xj - xi;
+    const murb_f2 dy = yj - yi;
+    const murb_f2 dz = zj - zi;
+    murb_f2 r2 = __builtin_elementwise_fma(dx, dx, (murb_f2)(soft2));
+    r2 = __builtin_elementwise_fma(dy, dy, r2);
+    r2 = __builtin_elementwise_fma(dz, dz, r2);
+    murb_f2 inv;
+    inv.x = __builtin_amdgcn_rsqf(r2.x);
+    inv.y = __builtin_amdgcn_rsqf(r2.y);
+    const murb_f2 inv3 = (inv * inv) * inv;
+    const murb_f2 fi = gj * inv3;          // pull of j on i
+    const murb_f2 fj = inv3 * (-gi);       // pull of i on j (opposite direction)
+    aix = __builtin_elementwise_fma(fi, dx, aix);
+    aiy = __builtin_elementwise_fma(fi, dy, aiy);
+    aiz = __builtin_elementwise_fma(fi, dz, aiz);
+    ajx = __builtin_elementwise_fma(fj, dx, ajx);
+    ajy = __builtin_elementwise_fma(fj, dy, ajy);
+    ajz = __builtin_elementwise_fma(fj, dz, ajz);
+}
+
+// grid.x = T (T + 1) / 2 items; 256 threads.  MINW = waves per SIMD the register allocator must allow.
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSymArgs a)
+{
+    constexpr int R = MURB_SYM_R;
+    __shared__ float4 tileA[MURB_SYM_PAIRS];                    // {x0,x1,y0,y1} of the J block
+    __shared__ float4 tileB[MURB_SYM_PAIRS];                    // {z0,z1,gm0,gm1}
+    __shared__ murb_f2 scratch[2][3][MURB_SYM_PAIRS];           // cross-wave combine of the j-side sums
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // item -> (I, J), I <= J: items are numbered row by row of the upper triangle
+    const int T = a.nblocks;
+    int I, J;
+    {
+        const long k = blockIdx.x;
+        // row I starts at offset I*T - I*(I-1)/2
+        int guess = (int)((2.0 * T + 1.0 - __builtin_sqrt((2.0 * T + 1.0) * (2.0 * T + 1.0) - 8.0 * (double)k)) * 0.5);
+        if (guess < 0) guess = 0;
+        if (guess > T - 1) guess = T - 1;
+        while (guess > 0 && (long)guess * T - (long)guess * (guess - 1) / 2 > k) --guess;
+        while (guess < T - 1 && (long)(guess + 1) * T - (long)(guess + 1) * guess / 2 <= k) ++guess;
+        I = guess;
+        J = I + (int)(k - ((long)I * T - (long)I * (I - 1) / 2));
+    }
+    I = __builtin_amdgcn_readfirstlane(I);
+    J = __builtin_amdgcn_readfirstlane(J);
+    const float soft2 = a.soft2;
+
+    // stage the J block: 2 layout tiles, A records to tileA, B records to tileB
+    {
+        const float4* src = a.rec + (unsigned long)(a.first_block + J) * (MURB_SYM_BLOCK / MURB_TILE_BODIES) * MURB_TILE_F4;
+#pragma unroll
+        for (int k = threadIdx.x; k < 2 * MURB_TILE_F4; k += 256) {
+            const int tile = k / MURB_TILE_F4, in = k % MURB_TILE_F4;
+            const float4 v = src[k];
+            if (in < MURB_TILE_PAIRS) tileA[tile * MURB_TILE_PAIRS + in] = v;
+            else tileB[tile * MURB_TILE_PAIRS + in - MURB_TILE_PAIRS] = v;
+        }
+    }
+    __syncthreads();
+
+    murb_f2 ajx[MURB_SYM_STEPS], ajy[MURB_SYM_STEPS], ajz[MURB_SYM_STEPS];
+#pragma unroll
+    for (int p = 0; p < MURB_SYM_STEPS; ++p) { ajx[p] = (murb_f2)(0.f); ajy[p] = (murb_f2)(0.f); ajz[p] = (murb_f2)(0.f); }
+
+    const int groups_per_wave = MURB_SYM_BLOCK / R / 4;      // 64
+    const unsigned int i_block_slot = (unsigned int)(a.first_block + I) * MURB_SYM_BLOCK;
+    const unsigned int i_local_slot = (unsigned int)I * MURB_SYM_BLOCK;
+    // where this lane's i-side total goes: value idx(lane) = 3 * body + component (see murb_reduce12)
+    unsigned long out_off;
+    {
+        const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
+        const int idx = b2 ? 8 + 2 * b4 + b5 : 4 * b3 + 2 * b4 + b5;
+        const int r = idx / 3, c = idx - 3 * r;
+        out_off = ((unsigned long)c * a.nrows + J) * a.row_stride + i_local_slot + r;
+    }
+#pragma unroll 1
+    for (int gk = 0; gk < groups_per_wave; ++gk) {
+        asm volatile("" ::: "memory");   // keep the tile reads inside the loop: 64 VGPRs of hoisted j data spill
+        const int g = gk * 4 + wave;                            // interleave the waves over the block
+        const unsigned int i_slot = i_block_slot + g * R;       // wave-uniform
+        float xi[R], yi[R], zi[R], gi[R];
+        {
+            const unsigned long ra = murb_rec_a((unsigned long)(i_slot >> 1));
+#pragma unroll
+            for (int h = 0; h < R / 2; ++h) {
+                const float4 A = a.rec[ra + h];
+                const float4 B = a.rec[ra + h + MURB_TILE_PAIRS];
+                xi[2 * h] = A.x; xi[2 * h + 1] = A.y;
+                yi[2 * h] = A.z; yi[2 * h + 1] = A.w;
+                zi[2 * h] = B.x; zi[2 * h + 1] = B.y;
+                gi[2 * h] = B.z; gi[2 * h + 1] = B.w;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                xi[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xi[r])));
+                yi[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, yi[r])));
+                zi[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, zi[r])));
+                gi[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, gi[r])));
+            }
+        }
+        murb_f2 aix[R], aiy[R], aiz[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { aix[r] = (murb_f2)(0.f); aiy[r] = (murb_f2)(0.f); aiz[r] = (murb_f2)(0.f); }
+
+#pragma unroll
+        for (int p = 0; p < MURB_SYM_STEPS; ++p) {
+            const float4 A = tileA[p * 64 + lane];
+            const float4 B = tileB[p * 64 + lane];
+            const murb_f2 xj = {A.x, A.y}, yj = {A.z, A.w}, zj = {B.x, B.y}, gj = {B.z, B.w};
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                murb_interact_sym(xj, yj, zj, gj, xi[r], yi[r], zi[r], gi[r], soft2, aix[r], aiy[r], aiz[r], ajx[p],
+                                  ajy[p], ajz[p]);
+            __builtin_amdgcn_sched_barrier(0);   // one step at a time: bounds the live temporaries
+        }
+
+        // i side: 12 sums -> lanes, one float per (body, component) -> partial row J
+        float v[12];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            v[3 * r + 0] = aix[r].x + aix[r].y;
+            v[3 * r + 1] = aiy[r].x + aiy[r].y;
+            v[3 * r + 2] = aiz[r].x + aiz[r].y;
+        }
+        const float total = murb_reduce12(v, lane);
+        // Every lane stores (no branch in the loop body: a conditional store here makes LLVM sink the
+        // j-side FMAs into the loop latch and spill 32 x 8 registers).  Lanes that hold the same total
+        // write the same value to the same address.
+        a.part[(unsigned long)out_off + g * R] = total;
+    }
+
+    // j side: combine the four waves in a fixed order (3+2 -> 1+0 -> 0), wave 0 writes partial row I
+    if (I != J) {
+        if (wave >= 2) {
+#pragma unroll
+            for (int p = 0; p < MURB_SYM_STEPS; ++p) {
+                scratch[wave - 2][0][p * 64 + lane] = ajx[p];
+                scratch[wave - 2][1][p * 64 + lane] = ajy[p];
+                scratch[wave - 2][2][p * 64 + lane] = ajz[p];
+            }
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+            for (int p = 0; p < MURB_SYM_STEPS; ++p) {
+                ajx[p] += scratch[wave][0][p * 64 + lane];
+                ajy[p] += scratch[wave][1][p * 64 + lane];
+                ajz[p] += scratch[wave][2][p * 64 + lane];
+            }
+        }
+        __syncthreads();
+        if (wave == 1) {
+#pragma unroll
+            for (int p = 0; p < MURB_SYM_STEPS; ++p) {
+                scratch[0][0][p * 64 + lane] = ajx[p];
+                scratch[0][1][p * 64 + lane] = ajy[p];
+                scratch[0][2][p * 64 + lane] = ajz[p];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const unsigned long base = (unsigned long)J * MURB_SYM_BLOCK;
+            murb_f2* px = reinterpret_cast<murb_f2*>(a.part + ((unsigned long)0 * a.nrows + I) * a.row_stride + base);
+            murb_f2* py = reinterpret_cast<murb_f2*>(a.part + ((unsigned long)1 * a.nrows + I) * a.row_stride + base);
+            murb_f2* pz = reinterpret_cast<murb_f2*>(a.part + ((unsigned long)2 * a.nrows + I) * a.row_stride + base);
+#pragma unroll
+            for (int p = 0; p < MURB_SYM_STEPS; ++p) {
+                px[p * 64 + lane] = ajx[p] + scratch[0][0][p * 64 + lane];
+                py[p * 64 + lane] = ajy[p] + scratch[0][1][p * 64 + lane];
+                pz[p * 64 + lane] = ajz[p] + scratch[0][2][p * 64 + lane];
+            }
+        }
+    }
+}
+
+// Adds the T partial rows of every body (fixed order) -> ax | ay | az.  Used by the lab and by
+// murbhip_compute_acc; the integrate kernel has the same loop built in.
+__global__ __launch_bounds__(256) void murb_sym_sum_rows(const float* part, int nrows_used, int nrows,
+                                                         unsigned int row_stride, float* out)
+{
+    const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= row_stride) return;
+    for (int c = 0; c < 3; ++c) {
+        float acc = 0.f;
+        for (int r = 0; r < nrows_used; ++r) acc += part[((unsigned long)c * nrows + r) * row_stride + s];
+        out[(unsigned long)c * row_stride + s] = acc;
+    }
+}
+
+#endif

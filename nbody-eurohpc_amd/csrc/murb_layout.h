@@ -33,10 +33,12 @@ MURB_HD unsigned long murb_rec_a(unsigned long pair)
     return (pair / MURB_TILE_PAIRS) * MURB_TILE_F4 + (pair % MURB_TILE_PAIRS);
 }
 
-/* Round a body count up to whole layout tiles. */
+#define MURB_SLICE_ALIGN 1024   /* slots: one block of the pair-symmetric kernel = 2 layout tiles */
+
+/* Round a body count up to whole slice units (also whole layout tiles). */
 MURB_HD unsigned long murb_round_up_tile(unsigned long bodies)
 {
-    return ((bodies + MURB_TILE_BODIES - 1) / MURB_TILE_BODIES) * MURB_TILE_BODIES;
+    return ((bodies + MURB_SLICE_ALIGN - 1) / MURB_SLICE_ALIGN) * MURB_SLICE_ALIGN;
 }
 
 #endif

@@ -23,7 +23,7 @@
 #include <vector>
 
 #include "../../include/murbhip.h"
-#include "murb_kernels.h"
+#include "murb_kernels_sym.h"
 
 namespace {
 
@@ -111,6 +111,7 @@ struct Shard {
     float4* vel = nullptr;
     float4* accp = nullptr;
     float* acc_out = nullptr;
+    float* sym_part = nullptr;   // pair-symmetric kernel: 3 planes of (slots/1024) rows, allocated on first use
     rccl_comm_t comm_rccl = nullptr;
     std::vector<hipEvent_t> prof;   // start/stop pairs around force launches
     size_t prof_used = 0;
@@ -150,6 +151,7 @@ struct Plan {
     int variant;   // resolved
     int parts_local, parts_remote;   // 2-D grid variants: j chunks of the own-slice launch and of the rest
     bool persistent;                 // balanced persistent schedule (murb_force_persistent)
+    bool symmetric;                  // pair-symmetric kernel (murb_force_sym_kernel), single shard only
     MurbSchedule sched[2];           // [0] own slice (or everything), [1] the rest
 };
 
@@ -174,9 +176,11 @@ int launch_force(int variant, const MurbForceArgs& a, int i_slots, hipStream_t s
         default: return MURBHIP_E_INVALID;
     }
 }
-constexpr int kNumVariants = 7;
-constexpr int kDefaultVariant = 1;   // the persistent schedule (7) measured no faster: DESIGN.md §4.1
+constexpr int kNumVariants = 8;
+constexpr int kOneSidedVariant = 1;     // the persistent schedule (7) measured no faster: DESIGN.md §4.1
 constexpr int kPersistentVariant = 7;   // murb_force_persistent<8, 4, 4>
+constexpr int kSymmetricVariant = 8;    // murb_force_sym_kernel<4>
+constexpr unsigned long kSymmetricMinBodies = 28672;   // below this too few block pairs to fill 256 CUs
 constexpr int kRowsPerLaunch = kMaxParts / 2;
 
 int launch_persistent(const MurbForceArgs& a, const MurbSchedule& sc, hipStream_t s)
@@ -218,6 +222,7 @@ int variant_group(int variant)   // bodies per workgroup = waves * R
 {
     switch (variant) {
         case kPersistentVariant: return 32;
+        case kSymmetricVariant: return 32;
         case 2: case 6: return 16;
         case 5: return 64;
         default: return 32;
@@ -240,7 +245,13 @@ int auto_parts(const murbhip_ctx* c, int variant, unsigned long i_slots, unsigne
 Plan make_plan(const murbhip_ctx* c)
 {
     Plan p{};
-    p.variant = (c->variant >= 1 && c->variant <= kNumVariants) ? c->variant : kDefaultVariant;
+    // variant 0 = auto: pair-symmetric on one GPU when there are enough block pairs, else one-sided
+    p.variant = (c->variant >= 1 && c->variant <= kNumVariants)
+                    ? c->variant
+                    : ((c->world == 1 && c->n >= kSymmetricMinBodies) ? kSymmetricVariant : kOneSidedVariant);
+    if (p.variant == kSymmetricVariant && c->world > 1) p.variant = kOneSidedVariant;   // remote pairs are one-sided
+    p.symmetric = p.variant == kSymmetricVariant;
+    if (p.symmetric) { p.persistent = false; p.parts_local = p.parts_remote = 0; return p; }
     const unsigned long tiles_local = c->slice / MURB_TILE_BODIES;
     const unsigned long tiles_remote = (c->slots - c->slice) / MURB_TILE_BODIES;
     p.persistent = p.variant == kPersistentVariant;
@@ -307,6 +318,29 @@ int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
         a.nchunks = p.parts_remote;
     }
     const int i_slots = (int)sh.count;   // the grid rounds up to whole i groups; the extra slots hold mass 0
+    if (p.symmetric) {
+        if (which != 0) return 0;
+        const int T = (int)(c->slots / MURB_SYM_BLOCK);
+        if (!sh.sym_part) {
+            const size_t bytes = (size_t)3 * T * c->slots * sizeof(float);
+            HIP_TRY(hipMalloc((void**)&sh.sym_part, bytes));
+            sh.bytes += bytes;
+        }
+        MurbSymArgs sa{};
+        sa.rec = sh.rec[c->cur];
+        sa.part = sh.sym_part;
+        sa.first_block = 0;
+        sa.nblocks = T;
+        sa.nrows = T;
+        sa.row_stride = (unsigned int)c->slots;
+        sa.soft2 = c->soft2;
+        RC_TRY(prof_begin(c, sh));
+        hipLaunchKernelGGL(murb_force_sym_kernel<4>, dim3((unsigned)((long)T * (T + 1) / 2)), dim3(256), 0, sh.compute, sa);
+        RC_TRY(hip_rc(hipGetLastError()));
+        RC_TRY(prof_end(c, sh));
+        c->interactions_per_launch = (double)c->n * (double)c->n;
+        return 0;
+    }
     if (p.persistent) {
         const MurbSchedule& sc = p.sched[which];
         if (sc.nblocks <= 0 || a.tiles.count <= 0) return 0;
@@ -326,6 +360,10 @@ int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
 int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int update_state, const Plan* plan = nullptr)
 {
     MurbIntegrateArgs a{};
+    if (plan && plan->symmetric) {
+        a.sym_part = sh.sym_part;
+        a.sym_rows = a.sym_nrows = (int)(c->slots / MURB_SYM_BLOCK);
+    }
     if (plan && plan->persistent) {
         a.group_bodies = 32;
         a.sched[0] = plan->sched[0];
@@ -639,7 +677,7 @@ int murbhip_destroy(murbhip_ctx* c)
         if (sh.ev_gathered) hipEventDestroy(sh.ev_gathered);
         if (sh.compute) hipStreamDestroy(sh.compute);
         if (sh.comm) hipStreamDestroy(sh.comm);
-        hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out);
+        hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out); hipFree(sh.sym_part);
     }
     delete c;
     return 0;

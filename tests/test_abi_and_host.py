@@ -56,7 +56,7 @@ def test_partition_is_the_reference_rule(mh, n, world):
         first += c
     assert first == n
     slots = mh.slice_slots(n, world)
-    assert slots % 512 == 0 and slots >= mh.partition(n, world, 0)[1] and slots - 512 < max(mh.partition(n, world, 0)[1], 1)
+    assert slots % 1024 == 0 and slots >= mh.partition(n, world, 0)[1] and slots - 1024 < max(mh.partition(n, world, 0)[1], 1)
     for i in {0, n // 2, n - 1, min(n - 1, n // world), min(n - 1, n // world + 1)}:
         s = mh.slot_of_body(n, world, i)
         r = s // slots

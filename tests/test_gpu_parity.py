@@ -161,7 +161,7 @@ def test_variants_and_jsplit_agree(gpu, O):
     s = O.init_bodies(n, "galaxy")
     truth = O.accel_f64(s, SOFT)
     base = gpu_acc(gpu, s)
-    for variant in range(1, 8):
+    for variant in range(1, 9):
         for jsplit in (1, 3, 7):
             a = gpu_acc(gpu, s, variant=variant, jsplit=jsplit)
             assert O.rel_err(a, truth).max() <= TOL_F64_MAX, (variant, jsplit)
