@@ -383,18 +383,24 @@ __global__ __launch_bounds__(256) void murb_integrate_kernel(const MurbIntegrate
 
     float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
     if (a.sym_part) {
-        // one partial row per block of the symmetric decomposition, added in row order
+        // one partial row per block of the symmetric decomposition, added in row order.  The rows are
+        // many (977 at N = 1M) and of similar size: they are summed in fp64 (memory-bound loop, free)
+        // so that the row sum adds no rounding of its own; one rounding to fp32 at the end.
         const float* px = a.sym_part + s0;
         const float* py = px + (unsigned long)a.sym_nrows * a.acc_stride;
         const float* pz = py + (unsigned long)a.sym_nrows * a.acc_stride;
+        double x0 = 0, x1 = 0, y0 = 0, y1 = 0, z0 = 0, z1 = 0;
         for (int r = 0; r < a.sym_rows; ++r) {
             const float2 u = *reinterpret_cast<const float2*>(px + (unsigned long)r * a.acc_stride);
             const float2 v = *reinterpret_cast<const float2*>(py + (unsigned long)r * a.acc_stride);
             const float2 w = *reinterpret_cast<const float2*>(pz + (unsigned long)r * a.acc_stride);
-            acc0.x += u.x; acc1.x += u.y;
-            acc0.y += v.x; acc1.y += v.y;
-            acc0.z += w.x; acc1.z += w.y;
+            x0 += (double)u.x; x1 += (double)u.y;
+            y0 += (double)v.x; y1 += (double)v.y;
+            z0 += (double)w.x; z1 += (double)w.y;
         }
+        acc0.x = (float)x0; acc1.x = (float)x1;
+        acc0.y = (float)y0; acc1.y = (float)y1;
+        acc0.z = (float)z0; acc1.z = (float)z1;
     } else if (a.nsched == 0) {
         for (int p = 0; p < a.nparts; ++p) {
             const float4 u = a.accp[(unsigned long)p * a.acc_stride + s0];
