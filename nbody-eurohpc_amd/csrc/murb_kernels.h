@@ -343,6 +343,7 @@ struct MurbIntegrateArgs {
     unsigned int acc_stride;
     float dt;
     int update_state;        // 0: only reduce partial sums into acc_out
+    const float* acc_planes; // complete accelerations ax | ay | az (acc_stride each), e.g. after a reduce-scatter
     const float* sym_part;   // pair-symmetric kernel: 3 planes [c][sym_nrows][acc_stride]; null otherwise
     int sym_rows, sym_nrows; // rows to add / rows per plane
     int nsched;              // persistent launches that produced accp (0, 1 or 2)
@@ -382,7 +383,11 @@ __global__ __launch_bounds__(256) void murb_integrate_kernel(const MurbIntegrate
     if (s0 >= (int)a.acc_stride) return;
 
     float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-    if (a.sym_part) {
+    if (a.acc_planes) {
+        acc0.x = a.acc_planes[s0]; acc1.x = a.acc_planes[s0 + 1];
+        acc0.y = a.acc_planes[a.acc_stride + s0]; acc1.y = a.acc_planes[a.acc_stride + s0 + 1];
+        acc0.z = a.acc_planes[2u * a.acc_stride + s0]; acc1.z = a.acc_planes[2u * a.acc_stride + s0 + 1];
+    } else if (a.sym_part) {
         // one partial row per block of the symmetric decomposition, added in row order.  The rows are
         // many (977 at N = 1M) and of similar size: they are summed in fp64 (memory-bound loop, free)
         // so that the row sum adds no rounding of its own; one rounding to fp32 at the end.

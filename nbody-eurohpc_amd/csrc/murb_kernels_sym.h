@@ -33,11 +33,12 @@
 
 struct MurbSymArgs {
     const float4* rec;     // body records (murb_layout.h)
-    float* part;           // partial sums, 3 planes: part[(c * nrows + row) * row_stride + local_slot]
-    int first_block;       // block index (in the record buffer) of local block 0
-    int nblocks;           // T: blocks of the (local) square being evaluated
-    int nrows;             // rows per plane (>= T)
-    unsigned int row_stride;   // floats per row (= local slots)
+    float* part;           // partial sums, 3 planes: part[(c * nrows + row) * row_stride + slot]
+    const int2* items;     // explicit (I, J) block pairs, or null: the whole upper triangle of nblocks
+    int item_first;        // first entry of `items` this launch evaluates
+    int nblocks;           // T: blocks of the square (items == null)
+    int nrows;             // rows per plane (>= number of blocks in the record buffer)
+    unsigned int row_stride;   // floats per row (= slots of the record buffer)
     float soft2;
 };
 
@@ -117,10 +118,15 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    // item -> (I, J), I <= J: items are numbered row by row of the upper triangle
-    const int T = a.nblocks;
+    // item -> (I, J): from the table (multi-rank half-ring schedule), or by numbering the upper
+    // triangle row by row (I <= J)
     int I, J;
-    {
+    if (a.items) {
+        const int2 it = a.items[a.item_first + blockIdx.x];
+        I = it.x;
+        J = it.y;
+    } else {
+        const int T = a.nblocks;
         const long k = blockIdx.x;
         // row I starts at offset I*T - I*(I-1)/2
         int guess = (int)((2.0 * T + 1.0 - __builtin_sqrt((2.0 * T + 1.0) * (2.0 * T + 1.0) - 8.0 * (double)k)) * 0.5);
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
 
     // stage the J block: 2 layout tiles, A records to tileA, B records to tileB
     {
-        const float4* src = a.rec + (unsigned long)(a.first_block + J) * (MURB_SYM_BLOCK / MURB_TILE_BODIES) * MURB_TILE_F4;
+        const float4* src = a.rec + (unsigned long)J * (MURB_SYM_BLOCK / MURB_TILE_BODIES) * MURB_TILE_F4;
 #pragma unroll
         for (int k = threadIdx.x; k < 2 * MURB_TILE_F4; k += 256) {
             const int tile = k / MURB_TILE_F4, in = k % MURB_TILE_F4;
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
     for (int p = 0; p < MURB_SYM_STEPS; ++p) { ajx[p] = (murb_f2)(0.f); ajy[p] = (murb_f2)(0.f); ajz[p] = (murb_f2)(0.f); }
 
     const int groups_per_wave = MURB_SYM_BLOCK / R / 4;      // 64
-    const unsigned int i_block_slot = (unsigned int)(a.first_block + I) * MURB_SYM_BLOCK;
+    const unsigned int i_block_slot = (unsigned int)I * MURB_SYM_BLOCK;
     const unsigned int i_local_slot = (unsigned int)I * MURB_SYM_BLOCK;
     // where this lane's i-side total goes: value idx(lane) = 3 * body + component (see murb_reduce12)
     unsigned long out_off;
@@ -263,18 +269,47 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
     }
 }
 
-// Adds the T partial rows of every body (fixed order) -> ax | ay | az.  Used by the lab and by
-// murbhip_compute_acc; the integrate kernel has the same loop built in.
-__global__ __launch_bounds__(256) void murb_sym_sum_rows(const float* part, int nrows_used, int nrows,
-                                                         unsigned int row_stride, float* out)
+// Multi-rank schedule: which partial rows a rank has written for the bodies of each slice (up to
+// three ranges of block rows), and the row sum into the reduce-scatter send buffer, laid out as one
+// chunk per slice: send[slice][component][local slot].
+#define MURB_SYM_MAX_RANKS 64
+struct MurbSymRowRanges {
+    int nslices, blocks_per_slice;
+    int first[MURB_SYM_MAX_RANKS][3], count[MURB_SYM_MAX_RANKS][3];
+};
+
+__global__ __launch_bounds__(256) void murb_sym_rowsum_kernel(const float* part, int nrows, unsigned int row_stride,
+                                                              const MurbSymRowRanges* rr_ptr, float* send)
 {
     const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= row_stride) return;
-    for (int c = 0; c < 3; ++c) {
-        float acc = 0.f;
-        for (int r = 0; r < nrows_used; ++r) acc += part[((unsigned long)c * nrows + r) * row_stride + s];
-        out[(unsigned long)c * row_stride + s] = acc;
+    const MurbSymRowRanges& rr = *rr_ptr;
+    const unsigned int slice_slots = (unsigned int)rr.blocks_per_slice * MURB_SYM_BLOCK;
+    const unsigned int sl = s / slice_slots, local = s - sl * slice_slots;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int k = 0; k < 3; ++k) {
+        const int r0 = rr.first[sl][k], r1 = r0 + rr.count[sl][k];
+        for (int r = r0; r < r1; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] += (double)part[((unsigned long)c * nrows + r) * row_stride + s];
     }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) send[((unsigned long)sl * 3 + c) * slice_slots + local] = (float)acc[c];
+}
+
+// Reduce-scatter by peer reads (one process, several shards): out = sum over shards of their chunk.
+struct MurbPeerPtrs {
+    const float* p[MURB_SYM_MAX_RANKS];
+    int n;
+};
+__global__ __launch_bounds__(256) void murb_sym_peer_sum_kernel(const MurbPeerPtrs peers, unsigned long chunk_offset,
+                                                                unsigned int count, float* out)
+{
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    float acc = 0.f;
+    for (int r = 0; r < peers.n; ++r) acc += peers.p[r][chunk_offset + k];   // rank order: reproducible
+    out[k] = acc;
 }
 
 #endif

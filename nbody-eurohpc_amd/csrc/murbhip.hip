@@ -54,12 +54,14 @@ struct Rccl {
     int (*CommInitAll)(rccl_comm_t*, int, const int*) = nullptr;
     int (*CommDestroy)(rccl_comm_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
 };
 constexpr int kRcclFloat = 7;   // ncclFloat32
+constexpr int kRcclSum = 0;     // ncclSum
 
 Rccl& rccl()
 {
@@ -76,10 +78,12 @@ Rccl& rccl()
     r.CommInitAll = (int (*)(rccl_comm_t*, int, const int*))dlsym(r.lib, "ncclCommInitAll");
     r.CommDestroy = (int (*)(rccl_comm_t))dlsym(r.lib, "ncclCommDestroy");
     r.AllGather = (int (*)(const void*, void*, size_t, int, rccl_comm_t, hipStream_t))dlsym(r.lib, "ncclAllGather");
+    r.ReduceScatter =
+        (int (*)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(r.lib, "ncclReduceScatter");
     r.GroupStart = (int (*)())dlsym(r.lib, "ncclGroupStart");
     r.GroupEnd = (int (*)())dlsym(r.lib, "ncclGroupEnd");
     r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
-    r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllGather && r.GroupStart &&
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllGather && r.ReduceScatter && r.GroupStart &&
            r.GroupEnd;
     return r;
 }
@@ -112,6 +116,13 @@ struct Shard {
     float4* accp = nullptr;
     float* acc_out = nullptr;
     float* sym_part = nullptr;   // pair-symmetric kernel: 3 planes of (slots/1024) rows, allocated on first use
+    // multi-rank pair-symmetric schedule (half ring): item table, row ranges, reduce-scatter buffers
+    int2* sym_items = nullptr;
+    int sym_items_own = 0, sym_items_total = 0;   // [0, own) = own-slice triangle, the rest need the gathered positions
+    MurbSymRowRanges* sym_ranges = nullptr;
+    float* sym_send = nullptr;   // [world][3][slice]
+    float* sym_recv = nullptr;   // [3][slice]
+    hipEvent_t ev_rowsum = nullptr, ev_reduced = nullptr;
     rccl_comm_t comm_rccl = nullptr;
     std::vector<hipEvent_t> prof;   // start/stop pairs around force launches
     size_t prof_used = 0;
@@ -249,7 +260,12 @@ Plan make_plan(const murbhip_ctx* c)
     p.variant = (c->variant >= 1 && c->variant <= kNumVariants)
                     ? c->variant
                     : ((c->world == 1 && c->n >= kSymmetricMinBodies) ? kSymmetricVariant : kOneSidedVariant);
-    if (p.variant == kSymmetricVariant && c->world > 1) p.variant = kOneSidedVariant;   // remote pairs are one-sided
+    if (c->variant == 0 && c->world > 1) {
+        // half-ring pair-symmetric schedule when every rank gets enough block pairs to fill its GPU
+        const long tb = (long)(c->slice / MURB_SYM_BLOCK), w = c->world;
+        const long items = tb * (tb + 1) / 2 + ((w - 1) / 2) * tb * tb + (w % 2 == 0 ? tb * ((tb + 1) / 2) : 0);
+        p.variant = items >= 400 ? kSymmetricVariant : kOneSidedVariant;
+    }
     p.symmetric = p.variant == kSymmetricVariant;
     if (p.symmetric) { p.persistent = false; p.parts_local = p.parts_remote = 0; return p; }
     const unsigned long tiles_local = c->slice / MURB_TILE_BODIES;
@@ -329,7 +345,8 @@ int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
         MurbSymArgs sa{};
         sa.rec = sh.rec[c->cur];
         sa.part = sh.sym_part;
-        sa.first_block = 0;
+        sa.items = nullptr;
+        sa.item_first = 0;
         sa.nblocks = T;
         sa.nrows = T;
         sa.row_stride = (unsigned int)c->slots;
@@ -438,10 +455,175 @@ int enqueue_exchange(murbhip_ctx* c, int buf)
     return 0;
 }
 
+// ---- pair-symmetric schedule over several ranks ("half ring") --------------------------------------
+// Rank r evaluates, once each, the block pairs of (own slice x own slice) and of (own slice x slice
+// r+d) for d = 1 .. floor(W/2); for even W the pair of slices half a ring apart is shared: the lower
+// rank takes the first half of ITS blocks against all of the other's, the higher rank the rest.  Every
+// unordered body pair is evaluated by exactly one rank.  A rank's partial sums for ALL slices it
+// touched are then row-summed into one chunk per slice and combined with ONE reduce-scatter (each
+// rank receives the complete accelerations of its own bodies); positions travel as before.
+int build_sym_schedule(murbhip_ctx* c, Shard& sh)
+{
+    if (sh.sym_items) return 0;
+    const int W = c->world, r = sh.rank;
+    const int tb = (int)(c->slice / MURB_SYM_BLOCK);
+    std::vector<int2> items;
+    for (int i = 0; i < tb; ++i)
+        for (int j = i; j < tb; ++j) items.push_back(make_int2(r * tb + i, r * tb + j));
+    const int own = (int)items.size();
+    MurbSymRowRanges rr{};
+    rr.nslices = W;
+    rr.blocks_per_slice = tb;
+    // own bodies: rows of slices r .. r + W/2 (cyclic) -> at most two ranges
+    const int span = std::min(W, W / 2 + 1);
+    const int end = r + span;   // exclusive, in slices, may pass W
+    rr.first[r][0] = r * tb;
+    rr.count[r][0] = (std::min(end, W) - r) * tb;
+    if (end > W) { rr.first[r][1] = 0; rr.count[r][1] = (end - W) * tb; }
+    for (int d = 1; d <= W / 2; ++d) {
+        const int s = (r + d) % W;
+        if (s == r) continue;
+        const bool shared = (W % 2 == 0) && d == W / 2;
+        const int lo = std::min(r, s);
+        const int half = (tb + 1) / 2;   // blocks of `lo` the lower rank takes
+        for (int i = 0; i < tb; ++i)
+            for (int j = 0; j < tb; ++j) {
+                // i indexes OWN blocks (walked, i side), j the other slice's blocks (LDS resident, j side)
+                if (shared) {
+                    const int lo_block = (r == lo) ? i : j;
+                    const bool mine = (r == lo) ? (lo_block < half) : (lo_block >= half);
+                    if (!mine) continue;
+                }
+                items.push_back(make_int2(r * tb + i, s * tb + j));
+            }
+        // bodies of slice s receive j-side sums in rows of OWN blocks
+        rr.first[s][0] = r * tb;
+        rr.count[s][0] = tb;
+    }
+    sh.sym_items_own = own;
+    sh.sym_items_total = (int)items.size();
+    HIP_TRY(hipMalloc((void**)&sh.sym_items, items.size() * sizeof(int2)));
+    HIP_TRY(hipMemcpy(sh.sym_items, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&sh.sym_ranges, sizeof rr));
+    HIP_TRY(hipMemcpy(sh.sym_ranges, &rr, sizeof rr, hipMemcpyHostToDevice));
+    const size_t chunk = (size_t)3 * c->slice * sizeof(float);
+    HIP_TRY(hipMalloc((void**)&sh.sym_send, chunk * W));
+    HIP_TRY(hipMalloc((void**)&sh.sym_recv, chunk));
+    HIP_TRY(hipEventCreateWithFlags(&sh.ev_rowsum, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sh.ev_reduced, hipEventDisableTiming));
+    if (!sh.sym_part) {
+        // cells this rank never writes must read as 0 in the row sum: zero once, they stay zero
+        const size_t bytes = (size_t)3 * (c->slots / MURB_SYM_BLOCK) * c->slots * sizeof(float);
+        HIP_TRY(hipMalloc((void**)&sh.sym_part, bytes));
+        HIP_TRY(hipMemset(sh.sym_part, 0, bytes));
+        sh.bytes += bytes;
+    }
+    sh.bytes += items.size() * sizeof(int2) + chunk * (W + 1);
+    return 0;
+}
+
+int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count)
+{
+    if (count <= 0) return 0;
+    MurbSymArgs sa{};
+    sa.rec = sh.rec[c->cur];
+    sa.part = sh.sym_part;
+    sa.items = sh.sym_items;
+    sa.item_first = first;
+    sa.nblocks = 0;
+    sa.nrows = (int)(c->slots / MURB_SYM_BLOCK);
+    sa.row_stride = (unsigned int)c->slots;
+    sa.soft2 = c->soft2;
+    RC_TRY(prof_begin(c, sh));
+    hipLaunchKernelGGL(murb_force_sym_kernel<4>, dim3((unsigned)count), dim3(256), 0, sh.compute, sa);
+    RC_TRY(hip_rc(hipGetLastError()));
+    RC_TRY(prof_end(c, sh));
+    return 0;
+}
+
+int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int update_state)
+{
+    const unsigned int chunk_floats = (unsigned int)(3 * c->slice);
+    for (Shard& sh : c->shards) {
+        HIP_TRY(hipSetDevice(sh.device));
+        RC_TRY(build_sym_schedule(c, sh));
+        if (c->overlap) {
+            RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_own));   // own slice: no remote data needed
+            if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
+            RC_TRY(enqueue_sym_launch(c, sh, sh.sym_items_own, sh.sym_items_total - sh.sym_items_own));
+        } else {
+            if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
+            RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_total));
+        }
+        hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)((c->slots + 255) / 256)), dim3(256), 0, sh.compute,
+                           sh.sym_part, (int)(c->slots / MURB_SYM_BLOCK), (unsigned int)c->slots, sh.sym_ranges,
+                           sh.sym_send);
+        RC_TRY(hip_rc(hipGetLastError()));
+        HIP_TRY(hipEventRecord(sh.ev_rowsum, sh.compute));
+        c->interactions_per_launch = (double)sh.count * (double)c->n;
+    }
+    // reduce-scatter: every rank ends up with the complete accelerations of its own slice
+    if (c->exchange == 1) {
+        Rccl& r = rccl();
+        for (Shard& sh : c->shards) {
+            HIP_TRY(hipSetDevice(sh.device));
+            HIP_TRY(hipStreamWaitEvent(sh.comm, sh.ev_rowsum, 0));
+        }
+        RC_TRY(nccl_rc(r.GroupStart()));
+        for (Shard& sh : c->shards) {
+            HIP_TRY(hipSetDevice(sh.device));
+            RC_TRY(nccl_rc(r.ReduceScatter(sh.sym_send, sh.sym_recv, chunk_floats, kRcclFloat, kRcclSum, sh.comm_rccl,
+                                           sh.comm)));
+        }
+        RC_TRY(nccl_rc(r.GroupEnd()));
+        for (Shard& sh : c->shards) {
+            HIP_TRY(hipSetDevice(sh.device));
+            HIP_TRY(hipEventRecord(sh.ev_reduced, sh.comm));
+            HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
+        }
+    } else {
+        MurbPeerPtrs peers{};
+        peers.n = (int)c->shards.size();
+        for (size_t k = 0; k < c->shards.size(); ++k) peers.p[c->shards[k].rank] = c->shards[k].sym_send;
+        for (Shard& sh : c->shards) {
+            HIP_TRY(hipSetDevice(sh.device));
+            for (Shard& peer : c->shards)
+                if (&peer != &sh) HIP_TRY(hipStreamWaitEvent(sh.compute, peer.ev_rowsum, 0));
+            hipLaunchKernelGGL(murb_sym_peer_sum_kernel, dim3((chunk_floats + 255) / 256), dim3(256), 0, sh.compute, peers,
+                               (unsigned long)sh.rank * chunk_floats, chunk_floats, sh.sym_recv);
+            RC_TRY(hip_rc(hipGetLastError()));
+        }
+    }
+    for (Shard& sh : c->shards) {
+        HIP_TRY(hipSetDevice(sh.device));
+        MurbIntegrateArgs a{};
+        a.rec_in = sh.rec[c->cur];
+        a.rec_out = sh.rec[c->cur ^ 1];
+        a.vel = sh.vel;
+        a.accp = sh.accp;
+        a.acc_out = sh.acc_out;
+        a.acc_planes = sh.sym_recv;
+        a.i_first_slot = (int)((unsigned long)sh.rank * c->slice);
+        a.count = (int)sh.count;
+        a.acc_stride = (unsigned int)c->slice;
+        a.dt = dt;
+        a.update_state = update_state;
+        hipLaunchKernelGGL(murb_integrate_kernel, dim3((unsigned)((c->slice / 2 + 255) / 256)), dim3(256), 0, sh.compute, a);
+        RC_TRY(hip_rc(hipGetLastError()));
+    }
+    if (update_state) {
+        RC_TRY(enqueue_exchange(c, c->cur ^ 1));
+        c->cur ^= 1;
+    }
+    (void)p;
+    return 0;
+}
+
 int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
 {
     const Plan p = make_plan(c);
     c->last_parts = p.parts_local + p.parts_remote;
+    if (p.symmetric && (c->world > 1 || c->force_exchange)) return enqueue_iteration_sym_multi(c, p, dt, update_state);
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
         if (c->world == 1) {
@@ -678,6 +860,9 @@ int murbhip_destroy(murbhip_ctx* c)
         if (sh.compute) hipStreamDestroy(sh.compute);
         if (sh.comm) hipStreamDestroy(sh.comm);
         hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out); hipFree(sh.sym_part);
+        hipFree(sh.sym_items); hipFree(sh.sym_ranges); hipFree(sh.sym_send); hipFree(sh.sym_recv);
+        if (sh.ev_rowsum) hipEventDestroy(sh.ev_rowsum);
+        if (sh.ev_reduced) hipEventDestroy(sh.ev_reduced);
     }
     delete c;
     return 0;

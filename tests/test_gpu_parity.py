@@ -193,16 +193,25 @@ def test_massless_bodies_do_not_pull(gpu, O):
     assert all(np.array_equal(bits(x), bits(y[:n])) for x, y in zip(a, a2))
 
 
-@pytest.mark.parametrize("shards", [2, 3])
-@pytest.mark.parametrize("overlap", [1, 0])
-def test_sharded_matches_single(gpu, O, shards, overlap):
-    """Body-range partition + per-step position exchange (two/three shards time-sharing one GPU)."""
-    n = 2049   # uneven slices: 1025 + 1024 / 683 + 683 + 683
+@pytest.mark.parametrize("shards", [2, 3, 4, 8])
+@pytest.mark.parametrize("variant,overlap", [(1, 1), (1, 0), (8, 1), (8, 0)])
+def test_sharded_matches_single(gpu, O, shards, variant, overlap):
+    """Body-range partition + per-step position exchange, several shards time-sharing one GPU.
+    variant 1: every rank sweeps all j for its own i slice (one-sided).  variant 8: half-ring
+    pair-symmetric schedule, every body pair evaluated by exactly one rank, accelerations combined by a
+    reduce-scatter (here its peer-read emulation)."""
+    n = 6151   # uneven slices
     s = O.init_bodies(n, "galaxy")
+    truth = O.accel_f64(s, SOFT)
     with gpu.Simulation(n, soft=SOFT) as one, gpu.Simulation(n, soft=SOFT, devices=[0] * shards) as many:
+        one.set_option("variant", 1)
+        many.set_option("variant", variant)
         many.set_option("overlap", overlap)
         one.upload(s)
         many.upload(s)
+        many.compute_acc()
+        many.sync()
+        assert O.rel_err(many.acc(), truth).max() <= TOL_F64_MAX
         for _ in range(4):
             one.step(DT)
             many.step(DT)
@@ -244,6 +253,18 @@ def test_rccl_binding_single_rank(gpu, O):
         a, b = one.state(), r0.state()
         for k in a:
             assert np.array_equal(bits(a[k]), bits(b[k])), k
+    # the pair-symmetric multi-rank path: item table + row sum + ncclReduceScatter (1 rank) + all-gather
+    uid = gpu.unique_id()   # a unique id founds exactly one communicator
+    with gpu.Simulation(n, soft=SOFT) as one, gpu.Simulation(n, soft=SOFT, rank=0, world=1, uid=uid) as r0:
+        one.set_option("variant", 8)
+        r0.set_option("variant", 8)
+        r0.set_option("force_exchange", 1)
+        one.upload(s); r0.upload(s)
+        one.steps(DT, 3); r0.steps(DT, 3)
+        one.sync(); r0.sync()
+        a, b = one.state(), r0.state()
+        for k in ("qx", "qy", "qz"):
+            np.testing.assert_allclose(b[k], a[k], rtol=TOL_POS, atol=1.0)
 
 
 def test_errors_are_reported(gpu):
@@ -259,7 +280,7 @@ def test_errors_are_reported(gpu):
 
 
 # ---- BASELINE.json sizes: size-independent properties -------------------------------------------
-@pytest.mark.parametrize("n", [30000, 200000])
+@pytest.mark.parametrize("n", [30000, 200000, 1000000])
 def test_full_size_properties(gpu, O, n):
     s = O.init_bodies(n, "galaxy")
     with gpu.Simulation(n, soft=SOFT) as sim:

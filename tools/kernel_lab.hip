@@ -15,6 +15,18 @@
 
 #include "murb_kernels_sym.h"
 
+__global__ __launch_bounds__(256) void murb_sym_sum_rows(const float* part, int nrows_used, int nrows,
+                                                         unsigned int row_stride, float* out)
+{
+    const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= row_stride) return;
+    for (int c = 0; c < 3; ++c) {
+        float acc = 0.f;
+        for (int r = 0; r < nrows_used; ++r) acc += part[((unsigned long)c * nrows + r) * row_stride + s];
+        out[(unsigned long)c * row_stride + s] = acc;
+    }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     fprintf(stderr, "HIP error %d (%s) at %s:%d\n", (int)e_, hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
 
@@ -59,7 +71,7 @@ int main(int argc, char** argv)
     CK(hipMemset(d_part, 0xff, (size_t)3 * nrows * slots * sizeof(float)));   // NaN: any unwritten cell shows up
     float* d_sym; CK(hipMalloc(&d_sym, 3 * slots * sizeof(float)));
     MurbSymArgs sa{};
-    sa.rec = d_rec; sa.part = d_part; sa.first_block = 0; sa.nblocks = T; sa.nrows = nrows; sa.row_stride = (unsigned)slots;
+    sa.rec = d_rec; sa.part = d_part; sa.items = nullptr; sa.item_first = 0; sa.nblocks = T; sa.nrows = nrows; sa.row_stride = (unsigned)slots;
     sa.soft2 = soft * soft;
     const long items = (long)T * (T + 1) / 2;
 
