@@ -136,7 +136,7 @@ int murbhip_sync(murbhip_ctx* ctx);
 
 /* Integer options.  Keys:
  *   "variant"        force kernel variant (0 = auto: pair-symmetric kernel (8) on one GPU
- *                    from 28 672 bodies up, one-sided kernel (1) otherwise)
+ *                    from 18 432 bodies up, one-sided kernel (1) otherwise)
  *   "jsplit"         2-D grid variants: number of j-chunks a body's sum is split into; persistent
  *                    variant: scheduling rounds (workgroups per resident slot).  0 = auto
  *   "profile"        1: bracket every force kernel with HIP events (read with murbhip_get_info)

@@ -344,8 +344,6 @@ struct MurbIntegrateArgs {
     float dt;
     int update_state;        // 0: only reduce partial sums into acc_out
     const float* acc_planes; // complete accelerations ax | ay | az (acc_stride each), e.g. after a reduce-scatter
-    const float* sym_part;   // pair-symmetric kernel: 3 planes [c][sym_nrows][acc_stride]; null otherwise
-    int sym_rows, sym_nrows; // rows to add / rows per plane
     int nsched;              // persistent launches that produced accp (0, 1 or 2)
     int group_bodies;        // bodies per i group of those launches
     MurbSchedule sched[2];
@@ -387,25 +385,6 @@ __global__ __launch_bounds__(256) void murb_integrate_kernel(const MurbIntegrate
         acc0.x = a.acc_planes[s0]; acc1.x = a.acc_planes[s0 + 1];
         acc0.y = a.acc_planes[a.acc_stride + s0]; acc1.y = a.acc_planes[a.acc_stride + s0 + 1];
         acc0.z = a.acc_planes[2u * a.acc_stride + s0]; acc1.z = a.acc_planes[2u * a.acc_stride + s0 + 1];
-    } else if (a.sym_part) {
-        // one partial row per block of the symmetric decomposition, added in row order.  The rows are
-        // many (977 at N = 1M) and of similar size: they are summed in fp64 (memory-bound loop, free)
-        // so that the row sum adds no rounding of its own; one rounding to fp32 at the end.
-        const float* px = a.sym_part + s0;
-        const float* py = px + (unsigned long)a.sym_nrows * a.acc_stride;
-        const float* pz = py + (unsigned long)a.sym_nrows * a.acc_stride;
-        double x0 = 0, x1 = 0, y0 = 0, y1 = 0, z0 = 0, z1 = 0;
-        for (int r = 0; r < a.sym_rows; ++r) {
-            const float2 u = *reinterpret_cast<const float2*>(px + (unsigned long)r * a.acc_stride);
-            const float2 v = *reinterpret_cast<const float2*>(py + (unsigned long)r * a.acc_stride);
-            const float2 w = *reinterpret_cast<const float2*>(pz + (unsigned long)r * a.acc_stride);
-            x0 += (double)u.x; x1 += (double)u.y;
-            y0 += (double)v.x; y1 += (double)v.y;
-            z0 += (double)w.x; z1 += (double)w.y;
-        }
-        acc0.x = (float)x0; acc1.x = (float)x1;
-        acc0.y = (float)y0; acc1.y = (float)y1;
-        acc0.z = (float)z0; acc1.z = (float)z1;
     } else if (a.nsched == 0) {
         for (int p = 0; p < a.nparts; ++p) {
             const float4 u = a.accp[(unsigned long)p * a.acc_stride + s0];

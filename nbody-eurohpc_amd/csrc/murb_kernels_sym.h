@@ -11,16 +11,20 @@
 // workgroup takes one block pair (I <= J):
 //   * the J block (512 pairs) is staged in LDS once; lane l of every wave owns j-pairs l, l+64, ...
 //     (8 per lane) and keeps their 24 packed accumulators in VGPRs for the whole item;
-//   * the 4 waves split the I block: a wave walks its 64 i groups of R = 4 bodies (coordinates and
-//     G*m in SGPRs), 8 fully unrolled steps per group;
+//   * the 4 waves split the I (sub-)block: a wave walks its 64/split i groups of R = 4 bodies
+//     (coordinates and G*m in SGPRs), 8 fully unrolled steps per group;
 //   * after a group the 12 i-side sums (4 bodies x 3) are spread over 64 lanes x 2 halves; they are
 //     folded with a transposing reduction (v_permlane32_swap / v_permlane16_swap, then DPP row
 //     mirrors with a select): 39 instructions instead of 12 x 11, and written to partial row J;
 //   * at the end the four waves' j-side sums are combined through LDS in a fixed order and written
 //     to partial row I.  Diagonal items (I == J) evaluate the full square and only keep the i side.
-// Every (row r, block K) cell of the partial-sum planes is written exactly once per launch (by item
-// (min(r,K), max(r,K))), so nothing needs zeroing and the row sum in the integrate kernel is
-// bit-reproducible.
+// Partial sums live in 3 planes of split*T rows.  Item (Isub, J) writes the i-side sums of its
+// sub-block's bodies to row split*J and the j-side sums of block J's bodies to row Isub: for a body of
+// block B the rows [0, split*B) hold j-side cells and the rows split*J (J >= B) i-side cells; every
+// cell has exactly one writer per launch, the remaining rows are never written (zeroed once at
+// allocation).  No atomics: the row sum is bit-reproducible.
+// `split` (1, 2, 4) cuts the i side of an item into sub-blocks: more, shorter items for small
+// problems and for the per-rank share of a multi-GPU run.
 #ifndef MURB_KERNELS_SYM_H_
 #define MURB_KERNELS_SYM_H_
 
@@ -34,10 +38,11 @@
 struct MurbSymArgs {
     const float4* rec;     // body records (murb_layout.h)
     float* part;           // partial sums, 3 planes: part[(c * nrows + row) * row_stride + slot]
-    const int2* items;     // explicit (I, J) block pairs, or null: the whole upper triangle of nblocks
+    const int2* items;     // (Isub, J) per workgroup: the i side walks sub-block Isub (1024/split slots),
+                           // the j side is block J; block(Isub) = Isub / split <= J, equal = diagonal item
     int item_first;        // first entry of `items` this launch evaluates
-    int nblocks;           // T: blocks of the square (items == null)
-    int nrows;             // rows per plane (>= number of blocks in the record buffer)
+    int split;             // sub-blocks per block on the i side: 1, 2 or 4 (finer items for small problems)
+    int nrows;             // rows per plane = split * (blocks in the record buffer)
     unsigned int row_stride;   // floats per row (= slots of the record buffer)
     float soft2;
 };
@@ -118,24 +123,12 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    // item -> (I, J): from the table (multi-rank half-ring schedule), or by numbering the upper
-    // triangle row by row (I <= J)
+    // item -> (Isub, J) from the host-built table
     int I, J;
-    if (a.items) {
+    {
         const int2 it = a.items[a.item_first + blockIdx.x];
         I = it.x;
         J = it.y;
-    } else {
-        const int T = a.nblocks;
-        const long k = blockIdx.x;
-        // row I starts at offset I*T - I*(I-1)/2
-        int guess = (int)((2.0 * T + 1.0 - __builtin_sqrt((2.0 * T + 1.0) * (2.0 * T + 1.0) - 8.0 * (double)k)) * 0.5);
-        if (guess < 0) guess = 0;
-        if (guess > T - 1) guess = T - 1;
-        while (guess > 0 && (long)guess * T - (long)guess * (guess - 1) / 2 > k) --guess;
-        while (guess < T - 1 && (long)(guess + 1) * T - (long)(guess + 1) * guess / 2 <= k) ++guess;
-        I = guess;
-        J = I + (int)(k - ((long)I * T - (long)I * (I - 1) / 2));
     }
     I = __builtin_amdgcn_readfirstlane(I);
     J = __builtin_amdgcn_readfirstlane(J);
@@ -158,16 +151,18 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
 #pragma unroll
     for (int p = 0; p < MURB_SYM_STEPS; ++p) { ajx[p] = (murb_f2)(0.f); ajy[p] = (murb_f2)(0.f); ajz[p] = (murb_f2)(0.f); }
 
-    const int groups_per_wave = MURB_SYM_BLOCK / R / 4;      // 64
-    const unsigned int i_block_slot = (unsigned int)I * MURB_SYM_BLOCK;
-    const unsigned int i_local_slot = (unsigned int)I * MURB_SYM_BLOCK;
+    const int split = a.split;
+    const bool diagonal = (I / split) == J;
+    const int groups_per_wave = MURB_SYM_BLOCK / R / 4 / split;      // 64, 32 or 16
+    const unsigned int i_block_slot = (unsigned int)I * (unsigned int)(MURB_SYM_BLOCK / split);
+    const unsigned int i_local_slot = i_block_slot;
     // where this lane's i-side total goes: value idx(lane) = 3 * body + component (see murb_reduce12)
     unsigned long out_off;
     {
         const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
         const int idx = b2 ? 8 + 2 * b4 + b5 : 4 * b3 + 2 * b4 + b5;
         const int r = idx / 3, c = idx - 3 * r;
-        out_off = ((unsigned long)c * a.nrows + J) * a.row_stride + i_local_slot + r;
+        out_off = ((unsigned long)c * a.nrows + (unsigned long)split * J) * a.row_stride + i_local_slot + r;
     }
 #pragma unroll 1
     for (int gk = 0; gk < groups_per_wave; ++gk) {
@@ -226,7 +221,7 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
     }
 
     // j side: combine the four waves in a fixed order (3+2 -> 1+0 -> 0), wave 0 writes partial row I
-    if (I != J) {
+    if (!diagonal) {
         if (wave >= 2) {
 #pragma unroll
             for (int p = 0; p < MURB_SYM_STEPS; ++p) {
@@ -275,26 +270,53 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
 #define MURB_SYM_MAX_RANKS 64
 struct MurbSymRowRanges {
     int nslices, blocks_per_slice;
-    int first[MURB_SYM_MAX_RANKS][3], count[MURB_SYM_MAX_RANKS][3];
+    int first[MURB_SYM_MAX_RANKS][3], count[MURB_SYM_MAX_RANKS][3], stride[MURB_SYM_MAX_RANKS][3];
 };
 
+// 256 threads = 64 consecutive slots x 4 row groups: row group g adds rows g, g+4, ... of every range
+// (fp64), the four partial sums are combined in a fixed order through LDS.  rr_ptr == null means one
+// rank owning everything (triangular schedule): the ranges follow from the slot's block B —
+// rows [0, split*B) hold j-side cells, rows split*J for J = B .. T-1 hold i-side cells.
 __global__ __launch_bounds__(256) void murb_sym_rowsum_kernel(const float* part, int nrows, unsigned int row_stride,
-                                                              const MurbSymRowRanges* rr_ptr, float* send)
+                                                              const MurbSymRowRanges* rr_ptr, int split, float* send)
 {
-    const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= row_stride) return;
-    const MurbSymRowRanges& rr = *rr_ptr;
-    const unsigned int slice_slots = (unsigned int)rr.blocks_per_slice * MURB_SYM_BLOCK;
-    const unsigned int sl = s / slice_slots, local = s - sl * slice_slots;
+    __shared__ double red[3][3][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const unsigned int s = blockIdx.x * 64 + lane;   // row_stride is a multiple of 1024: no partial block
+    int first[3], count[3], stride[3];
+    unsigned int sl = 0, local = s, slice_slots = row_stride;
+    if (rr_ptr) {
+        slice_slots = (unsigned int)rr_ptr->blocks_per_slice * MURB_SYM_BLOCK;
+        sl = s / slice_slots;
+        local = s - sl * slice_slots;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { first[k] = rr_ptr->first[sl][k]; count[k] = rr_ptr->count[sl][k]; stride[k] = rr_ptr->stride[sl][k]; }
+    } else {
+        const int B = (int)(s / MURB_SYM_BLOCK), T = nrows / split;
+        first[0] = 0; count[0] = split * B; stride[0] = 1;
+        first[1] = split * B; count[1] = T - B; stride[1] = split;
+        first[2] = 0; count[2] = 0; stride[2] = 1;
+    }
     double acc[3] = {0.0, 0.0, 0.0};
-    for (int k = 0; k < 3; ++k) {
-        const int r0 = rr.first[sl][k], r1 = r0 + rr.count[sl][k];
-        for (int r = r0; r < r1; ++r)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int idx = g; idx < count[k]; idx += 4) {
+            const unsigned long r = (unsigned long)(first[k] + idx * stride[k]);
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc[c] += (double)part[((unsigned long)c * nrows + r) * row_stride + s];
-    }
+        }
+    if (g > 0) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) send[((unsigned long)sl * 3 + c) * slice_slots + local] = (float)acc[c];
+        for (int c = 0; c < 3; ++c) red[g - 1][c][lane] = acc[c];
+    }
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double total = ((acc[c] + red[0][c][lane]) + red[1][c][lane]) + red[2][c][lane];
+            send[((unsigned long)sl * 3 + c) * slice_slots + local] = (float)total;
+        }
+    }
 }
 
 // Reduce-scatter by peer reads (one process, several shards): out = sum over shards of their chunk.

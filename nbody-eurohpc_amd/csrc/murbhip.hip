@@ -119,6 +119,7 @@ struct Shard {
     // multi-rank pair-symmetric schedule (half ring): item table, row ranges, reduce-scatter buffers
     int2* sym_items = nullptr;
     int sym_items_own = 0, sym_items_total = 0;   // [0, own) = own-slice triangle, the rest need the gathered positions
+    int sym_split = 0;                            // i-side sub-blocks per block the table was built for
     MurbSymRowRanges* sym_ranges = nullptr;
     float* sym_send = nullptr;   // [world][3][slice]
     float* sym_recv = nullptr;   // [3][slice]
@@ -162,7 +163,8 @@ struct Plan {
     int variant;   // resolved
     int parts_local, parts_remote;   // 2-D grid variants: j chunks of the own-slice launch and of the rest
     bool persistent;                 // balanced persistent schedule (murb_force_persistent)
-    bool symmetric;                  // pair-symmetric kernel (murb_force_sym_kernel), single shard only
+    bool symmetric;                  // pair-symmetric kernel (murb_force_sym_kernel)
+    int split;                       // its i-side sub-blocks per block (1, 2, 4)
     MurbSchedule sched[2];           // [0] own slice (or everything), [1] the rest
 };
 
@@ -191,7 +193,7 @@ constexpr int kNumVariants = 8;
 constexpr int kOneSidedVariant = 1;     // the persistent schedule (7) measured no faster: DESIGN.md §4.1
 constexpr int kPersistentVariant = 7;   // murb_force_persistent<8, 4, 4>
 constexpr int kSymmetricVariant = 8;    // murb_force_sym_kernel<4>
-constexpr unsigned long kSymmetricMinBodies = 28672;   // below this too few block pairs to fill 256 CUs
+constexpr unsigned long kSymmetricMinBodies = 18432;   // below this the one-sided kernel wins (tools/sweep.py)
 constexpr int kRowsPerLaunch = kMaxParts / 2;
 
 int launch_persistent(const MurbForceArgs& a, const MurbSchedule& sc, hipStream_t s)
@@ -267,7 +269,16 @@ Plan make_plan(const murbhip_ctx* c)
         p.variant = items >= 400 ? kSymmetricVariant : kOneSidedVariant;
     }
     p.symmetric = p.variant == kSymmetricVariant;
-    if (p.symmetric) { p.persistent = false; p.parts_local = p.parts_remote = 0; return p; }
+    if (p.symmetric) {
+        // finer items (i side cut in 2 or 4) until a rank has ~16 scheduling rounds of them
+        const long tb = (long)(c->slice / MURB_SYM_BLOCK), w = c->world;
+        const long items = tb * (tb + 1) / 2 + ((w - 1) / 2) * tb * tb + (w % 2 == 0 && w > 1 ? tb * ((tb + 1) / 2) : 0);
+        const long want = 8L * 4 * std::max(c->cu_count, 1);
+        p.split = (c->jsplit == 1 || c->jsplit == 2 || c->jsplit == 4) ? c->jsplit : (items >= want ? 1 : (2 * items >= want ? 2 : 4));
+        p.persistent = false;
+        p.parts_local = p.parts_remote = 0;
+        return p;
+    }
     const unsigned long tiles_local = c->slice / MURB_TILE_BODIES;
     const unsigned long tiles_remote = (c->slots - c->slice) / MURB_TILE_BODIES;
     p.persistent = p.variant == kPersistentVariant;
@@ -313,6 +324,9 @@ int prof_end(murbhip_ctx* c, Shard& sh)
     return rc;
 }
 
+int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split);
+int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count);
+
 // Force over the tiles of `which` (0 = own slice / everything when world == 1, 1 = all but own slice).
 int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
 {
@@ -334,27 +348,14 @@ int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
         a.nchunks = p.parts_remote;
     }
     const int i_slots = (int)sh.count;   // the grid rounds up to whole i groups; the extra slots hold mass 0
-    if (p.symmetric) {
+    if (p.symmetric) {   // one shard, no exchange: the whole triangle in one launch
         if (which != 0) return 0;
-        const int T = (int)(c->slots / MURB_SYM_BLOCK);
-        if (!sh.sym_part) {
-            const size_t bytes = (size_t)3 * T * c->slots * sizeof(float);
-            HIP_TRY(hipMalloc((void**)&sh.sym_part, bytes));
-            sh.bytes += bytes;
-        }
-        MurbSymArgs sa{};
-        sa.rec = sh.rec[c->cur];
-        sa.part = sh.sym_part;
-        sa.items = nullptr;
-        sa.item_first = 0;
-        sa.nblocks = T;
-        sa.nrows = T;
-        sa.row_stride = (unsigned int)c->slots;
-        sa.soft2 = c->soft2;
-        RC_TRY(prof_begin(c, sh));
-        hipLaunchKernelGGL(murb_force_sym_kernel<4>, dim3((unsigned)((long)T * (T + 1) / 2)), dim3(256), 0, sh.compute, sa);
+        RC_TRY(build_sym_schedule(c, sh, p.split));
+        RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_total));
+        hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slots / 64)), dim3(256), 0, sh.compute,
+                           sh.sym_part, sh.sym_split * (int)(c->slots / MURB_SYM_BLOCK), (unsigned int)c->slots,
+                           (const MurbSymRowRanges*)nullptr, sh.sym_split, sh.sym_recv);
         RC_TRY(hip_rc(hipGetLastError()));
-        RC_TRY(prof_end(c, sh));
         c->interactions_per_launch = (double)c->n * (double)c->n;
         return 0;
     }
@@ -377,10 +378,7 @@ int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
 int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int update_state, const Plan* plan = nullptr)
 {
     MurbIntegrateArgs a{};
-    if (plan && plan->symmetric) {
-        a.sym_part = sh.sym_part;
-        a.sym_rows = a.sym_nrows = (int)(c->slots / MURB_SYM_BLOCK);
-    }
+    if (plan && plan->symmetric) a.acc_planes = sh.sym_recv;   // written by murb_sym_rowsum_kernel
     if (plan && plan->persistent) {
         a.group_bodies = 32;
         a.sched[0] = plan->sched[0];
@@ -462,63 +460,80 @@ int enqueue_exchange(murbhip_ctx* c, int buf)
 // unordered body pair is evaluated by exactly one rank.  A rank's partial sums for ALL slices it
 // touched are then row-summed into one chunk per slice and combined with ONE reduce-scatter (each
 // rank receives the complete accelerations of its own bodies); positions travel as before.
-int build_sym_schedule(murbhip_ctx* c, Shard& sh)
+int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split)
 {
-    if (sh.sym_items) return 0;
+    if (sh.sym_items && sh.sym_split == split) return 0;
+    if (sh.sym_items) {   // option changed: rebuild (the planes are re-zeroed because the row meaning changes)
+        HIP_TRY(hipStreamSynchronize(sh.compute));
+        hipFree(sh.sym_items); sh.sym_items = nullptr;
+    }
     const int W = c->world, r = sh.rank;
-    const int tb = (int)(c->slice / MURB_SYM_BLOCK);
+    const int tb = (int)(c->slice / MURB_SYM_BLOCK);   // blocks per slice
+    const int ts = tb * split;                          // i-side sub-blocks per slice
     std::vector<int2> items;
-    for (int i = 0; i < tb; ++i)
-        for (int j = i; j < tb; ++j) items.push_back(make_int2(r * tb + i, r * tb + j));
+    // own slice x own slice: sub-block i against block j of the same slice, block(i) <= j
+    for (int j = 0; j < tb; ++j)
+        for (int i = 0; i < (j + 1) * split; ++i) items.push_back(make_int2(r * ts + i, r * tb + j));
     const int own = (int)items.size();
     MurbSymRowRanges rr{};
     rr.nslices = W;
     rr.blocks_per_slice = tb;
-    // own bodies: rows of slices r .. r + W/2 (cyclic) -> at most two ranges
-    const int span = std::min(W, W / 2 + 1);
-    const int end = r + span;   // exclusive, in slices, may pass W
-    rr.first[r][0] = r * tb;
-    rr.count[r][0] = (std::min(end, W) - r) * tb;
-    if (end > W) { rr.first[r][1] = 0; rr.count[r][1] = (end - W) * tb; }
+    for (int sl = 0; sl < W; ++sl)
+        for (int k = 0; k < 3; ++k) rr.stride[sl][k] = 1;
+    // own bodies: all rows of the own slice (j-side cells dense, i-side cells every `split`-th) ...
+    rr.first[r][0] = r * ts;
+    rr.count[r][0] = ts;
+    // ... and the i-side cells of the rectangles: rows split*J of slices r+1 .. r+W/2 (cyclic, <= 2 ranges)
+    const int far = W / 2;
+    if (far > 0 && W > 1) {
+        const int a0 = r + 1, a1 = r + 1 + far;   // slices [a0, a1)
+        rr.first[r][1] = a0 * ts; rr.count[r][1] = (std::min(a1, W) - a0) * tb; rr.stride[r][1] = split;
+        if (a0 >= W) { rr.first[r][1] = (a0 - W) * ts; rr.count[r][1] = far * tb; }
+        else if (a1 > W) { rr.first[r][2] = 0; rr.count[r][2] = (a1 - W) * tb; rr.stride[r][2] = split; }
+    }
     for (int d = 1; d <= W / 2; ++d) {
         const int s = (r + d) % W;
         if (s == r) continue;
         const bool shared = (W % 2 == 0) && d == W / 2;
         const int lo = std::min(r, s);
-        const int half = (tb + 1) / 2;   // blocks of `lo` the lower rank takes
-        for (int i = 0; i < tb; ++i)
+        for (int i = 0; i < ts; ++i)
             for (int j = 0; j < tb; ++j) {
-                // i indexes OWN blocks (walked, i side), j the other slice's blocks (LDS resident, j side)
+                // i: OWN sub-blocks (walked, i side); j: the other slice's blocks (LDS resident, j side)
                 if (shared) {
-                    const int lo_block = (r == lo) ? i : j;
-                    const bool mine = (r == lo) ? (lo_block < half) : (lo_block >= half);
+                    // the two ranks half a ring apart share this slice pair; it is cut at a block boundary of
+                    // the LOWER rank's slice: the lower rank walks its first hb blocks against all of the
+                    // other slice, the higher rank walks all of its own against the remaining blocks
+                    const int hb = (tb + 1) / 2;
+                    const bool mine = (r == lo) ? (i / split < hb) : (j >= hb);
                     if (!mine) continue;
                 }
-                items.push_back(make_int2(r * tb + i, s * tb + j));
+                items.push_back(make_int2(r * ts + i, s * tb + j));
             }
-        // bodies of slice s receive j-side sums in rows of OWN blocks
-        rr.first[s][0] = r * tb;
-        rr.count[s][0] = tb;
+        // bodies of slice s receive j-side sums in the rows of OWN sub-blocks
+        rr.first[s][0] = r * ts;
+        rr.count[s][0] = ts;
     }
     sh.sym_items_own = own;
     sh.sym_items_total = (int)items.size();
+    sh.sym_split = split;
     HIP_TRY(hipMalloc((void**)&sh.sym_items, items.size() * sizeof(int2)));
     HIP_TRY(hipMemcpy(sh.sym_items, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void**)&sh.sym_ranges, sizeof rr));
+    if (!sh.sym_ranges) HIP_TRY(hipMalloc((void**)&sh.sym_ranges, sizeof rr));
     HIP_TRY(hipMemcpy(sh.sym_ranges, &rr, sizeof rr, hipMemcpyHostToDevice));
     const size_t chunk = (size_t)3 * c->slice * sizeof(float);
-    HIP_TRY(hipMalloc((void**)&sh.sym_send, chunk * W));
-    HIP_TRY(hipMalloc((void**)&sh.sym_recv, chunk));
-    HIP_TRY(hipEventCreateWithFlags(&sh.ev_rowsum, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&sh.ev_reduced, hipEventDisableTiming));
-    if (!sh.sym_part) {
-        // cells this rank never writes must read as 0 in the row sum: zero once, they stay zero
-        const size_t bytes = (size_t)3 * (c->slots / MURB_SYM_BLOCK) * c->slots * sizeof(float);
-        HIP_TRY(hipMalloc((void**)&sh.sym_part, bytes));
-        HIP_TRY(hipMemset(sh.sym_part, 0, bytes));
-        sh.bytes += bytes;
+    if (!sh.sym_send) {
+        HIP_TRY(hipMalloc((void**)&sh.sym_send, chunk * W));
+        HIP_TRY(hipMalloc((void**)&sh.sym_recv, chunk));
+        HIP_TRY(hipEventCreateWithFlags(&sh.ev_rowsum, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sh.ev_reduced, hipEventDisableTiming));
+        sh.bytes += chunk * (W + 1);
     }
-    sh.bytes += items.size() * sizeof(int2) + chunk * (W + 1);
+    // cells nobody writes must read as 0 in the row sums: zero once per layout, they stay zero
+    const size_t bytes = (size_t)3 * split * (c->slots / MURB_SYM_BLOCK) * c->slots * sizeof(float);
+    if (sh.sym_part) { hipFree(sh.sym_part); sh.sym_part = nullptr; }
+    HIP_TRY(hipMalloc((void**)&sh.sym_part, bytes));
+    HIP_TRY(hipMemsetAsync(sh.sym_part, 0, bytes, sh.compute));   // on OUR stream: it is non-blocking w.r.t. stream 0
+    sh.bytes += bytes + items.size() * sizeof(int2);
     return 0;
 }
 
@@ -530,8 +545,8 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count)
     sa.part = sh.sym_part;
     sa.items = sh.sym_items;
     sa.item_first = first;
-    sa.nblocks = 0;
-    sa.nrows = (int)(c->slots / MURB_SYM_BLOCK);
+    sa.split = sh.sym_split;
+    sa.nrows = sh.sym_split * (int)(c->slots / MURB_SYM_BLOCK);
     sa.row_stride = (unsigned int)c->slots;
     sa.soft2 = c->soft2;
     RC_TRY(prof_begin(c, sh));
@@ -546,7 +561,7 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
     const unsigned int chunk_floats = (unsigned int)(3 * c->slice);
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
-        RC_TRY(build_sym_schedule(c, sh));
+        RC_TRY(build_sym_schedule(c, sh, p.split));
         if (c->overlap) {
             RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_own));   // own slice: no remote data needed
             if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
@@ -555,9 +570,9 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
             if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
             RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_total));
         }
-        hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)((c->slots + 255) / 256)), dim3(256), 0, sh.compute,
-                           sh.sym_part, (int)(c->slots / MURB_SYM_BLOCK), (unsigned int)c->slots, sh.sym_ranges,
-                           sh.sym_send);
+        hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slots / 64)), dim3(256), 0, sh.compute,
+                           sh.sym_part, sh.sym_split * (int)(c->slots / MURB_SYM_BLOCK), (unsigned int)c->slots,
+                           sh.sym_ranges, sh.sym_split, sh.sym_send);
         RC_TRY(hip_rc(hipGetLastError()));
         HIP_TRY(hipEventRecord(sh.ev_rowsum, sh.compute));
         c->interactions_per_launch = (double)sh.count * (double)c->n;

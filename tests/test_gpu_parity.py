@@ -162,7 +162,7 @@ def test_variants_and_jsplit_agree(gpu, O):
     truth = O.accel_f64(s, SOFT)
     base = gpu_acc(gpu, s)
     for variant in range(1, 9):
-        for jsplit in (1, 3, 7):
+        for jsplit in ((1, 2, 4) if variant == 8 else (1, 3, 7)):
             a = gpu_acc(gpu, s, variant=variant, jsplit=jsplit)
             assert O.rel_err(a, truth).max() <= TOL_F64_MAX, (variant, jsplit)
             assert O.rel_err(a, base).max() <= 2e-6
@@ -194,8 +194,8 @@ def test_massless_bodies_do_not_pull(gpu, O):
 
 
 @pytest.mark.parametrize("shards", [2, 3, 4, 8])
-@pytest.mark.parametrize("variant,overlap", [(1, 1), (1, 0), (8, 1), (8, 0)])
-def test_sharded_matches_single(gpu, O, shards, variant, overlap):
+@pytest.mark.parametrize("variant,overlap,jsplit", [(1, 1, 0), (1, 0, 0), (8, 1, 0), (8, 0, 1), (8, 1, 2)])
+def test_sharded_matches_single(gpu, O, shards, variant, overlap, jsplit):
     """Body-range partition + per-step position exchange, several shards time-sharing one GPU.
     variant 1: every rank sweeps all j for its own i slice (one-sided).  variant 8: half-ring
     pair-symmetric schedule, every body pair evaluated by exactly one rank, accelerations combined by a
@@ -207,6 +207,7 @@ def test_sharded_matches_single(gpu, O, shards, variant, overlap):
         one.set_option("variant", 1)
         many.set_option("variant", variant)
         many.set_option("overlap", overlap)
+        many.set_option("jsplit", jsplit)   # variant 8: i-side sub-blocks per item (0 = auto)
         one.upload(s)
         many.upload(s)
         many.compute_acc()

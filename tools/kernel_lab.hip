@@ -71,7 +71,11 @@ int main(int argc, char** argv)
     CK(hipMemset(d_part, 0xff, (size_t)3 * nrows * slots * sizeof(float)));   // NaN: any unwritten cell shows up
     float* d_sym; CK(hipMalloc(&d_sym, 3 * slots * sizeof(float)));
     MurbSymArgs sa{};
-    sa.rec = d_rec; sa.part = d_part; sa.items = nullptr; sa.item_first = 0; sa.nblocks = T; sa.nrows = nrows; sa.row_stride = (unsigned)slots;
+    std::vector<int2> h_items;
+    for (int j = 0; j < T; ++j) for (int i = 0; i <= j; ++i) h_items.push_back(make_int2(i, j));
+    int2* d_items; CK(hipMalloc(&d_items, h_items.size() * sizeof(int2)));
+    CK(hipMemcpy(d_items, h_items.data(), h_items.size() * sizeof(int2), hipMemcpyHostToDevice));
+    sa.rec = d_rec; sa.part = d_part; sa.items = d_items; sa.item_first = 0; sa.split = 1; sa.nrows = nrows; sa.row_stride = (unsigned)slots;
     sa.soft2 = soft * soft;
     const long items = (long)T * (T + 1) / 2;
 
