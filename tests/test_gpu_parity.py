@@ -227,6 +227,36 @@ def test_sharded_matches_single(gpu, O, shards, variant, overlap, jsplit):
             np.testing.assert_allclose(s2[k], s1[k], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("shards", [2, 4, 8])
+def test_sharded_benchmark_size(gpu, O, shards):
+    """N = 200 000 cut over 2/4/8 shards (BASELINE configs[3]) with the library's own choice of
+    schedule (half-ring pair-symmetric, auto split): spot check against the fp64 truth, momentum
+    balance, and two steps against the single-GPU run."""
+    n = 200000
+    s = O.init_bodies(n, "galaxy")
+    idx = np.random.default_rng(11).choice(n, 1024, replace=False)
+    truth = O.accel_f64_subset(s, idx, SOFT)
+    with gpu.Simulation(n, soft=SOFT) as one, gpu.Simulation(n, soft=SOFT, devices=[0] * shards) as many:
+        assert many.info("variant") == 8
+        one.upload(s)
+        many.upload(s)
+        many.compute_acc()
+        many.sync()
+        a = many.acc()
+        assert O.rel_err(tuple(c[idx] for c in a), truth).max() <= TOL_F64_MAX
+        m = s["m"].astype(np.float64)
+        tot = np.array([(m * c.astype(np.float64)).sum() for c in a])
+        scale = np.array([(m * np.abs(c.astype(np.float64))).sum() for c in a])
+        assert (np.abs(tot) / scale).max() <= 1e-6
+        one.steps(DT, 2)
+        many.steps(DT, 2)
+        one.sync()
+        many.sync()
+        s1, s2 = one.state(), many.state()
+        for k in ("qx", "qy", "qz"):
+            np.testing.assert_allclose(s2[k], s1[k], rtol=TOL_POS, atol=1.0)
+
+
 def test_rank_mode_single_rank(gpu, O):
     """One process per GPU entry point with world = 1 (RCCL not needed, same results)."""
     n = 2048
