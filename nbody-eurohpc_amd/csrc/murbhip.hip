@@ -274,7 +274,9 @@ Plan make_plan(const murbhip_ctx* c)
         const long tb = (long)(c->slice / MURB_SYM_BLOCK), w = c->world;
         const long items = tb * (tb + 1) / 2 + ((w - 1) / 2) * tb * tb + (w % 2 == 0 && w > 1 ? tb * ((tb + 1) / 2) : 0);
         const long want = 8L * 4 * std::max(c->cu_count, 1);
-        p.split = (c->jsplit == 1 || c->jsplit == 2 || c->jsplit == 4) ? c->jsplit : (items >= want ? 1 : (2 * items >= want ? 2 : 4));
+        p.split = (c->jsplit == 1 || c->jsplit == 2 || c->jsplit == 4 || c->jsplit == 8 || c->jsplit == 16)
+                      ? c->jsplit
+                      : (items >= want ? 1 : (2 * items >= want ? 2 : 4));
         p.persistent = false;
         p.parts_local = p.parts_remote = 0;
         return p;

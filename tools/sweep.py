@@ -21,5 +21,5 @@ if __name__ == "__main__":
     ns = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [30000, 200000]
     for n in ns:
         for v in (1, 8):
-            for js in ([1, 2, 4] if v == 8 else [0]):
+            for js in ([1, 2, 4, 8, 16] if v == 8 else [0]):
                 run(n, v, js, steps=20 if n <= 50000 else 6)
