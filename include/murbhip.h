@@ -132,6 +132,13 @@ int murbhip_integrate_host_acc(murbhip_ctx* ctx, const float* ax, const float* a
 /* Wait for everything enqueued on this context; returns the first asynchronous error, if any. */
 int murbhip_sync(murbhip_ctx* ctx);
 
+/* Mechanical energy of the current state: kinetic = sum 1/2 m v^2, potential = -1/2 sum_i sum_{j != i}
+ * G m_i m_j / sqrt(r_ij^2 + soft^2) — the per-iteration metric of the reference's gpu+tracking
+ * implementation (SimulationNBodyCUDAPropertyTracking.cu:217-304, summed there with cub).  One N^2
+ * potential sweep on the device, the O(N) sum in fp64 on the host; waits for enqueued steps.  In rank
+ * mode the values cover the caller's own bodies only (sum them over ranks). */
+int murbhip_energy(murbhip_ctx* ctx, double* kinetic, double* potential);
+
 /* ------------------------------------------------------------------ tuning and measurement */
 
 /* Integer options.  Keys:

@@ -107,10 +107,28 @@ __device__ __forceinline__ void murb_interact_sc(const float xj, const float yj,
     az = __builtin_fmaf(s, dz, az);
 }
 
+// Gravitational potential of i due to a j pair: phi_i += GM_j / sqrt(|d|^2 + soft^2) (sign and the
+// 1/2 m_i factor are applied by the caller).  Energy diagnostic of the reference's gpu+tracking
+// implementation (SimulationNBodyCUDAPropertyTracking.cu:217-304), not on the force path.
+__device__ __forceinline__ void murb_interact_phi(const murb_f2 xj, const murb_f2 yj, const murb_f2 zj, const murb_f2 gj,
+                                                  const float xi, const float yi, const float zi, const float soft2,
+                                                  murb_f2& phi)
+{
+    const murb_f2 dx = xj - xi, dy = yj - yi, dz = zj - zi;
+    murb_f2 r2 = __builtin_elementwise_fma(dx, dx, (murb_f2)(soft2));
+    r2 = __builtin_elementwise_fma(dy, dy, r2);
+    r2 = __builtin_elementwise_fma(dz, dz, r2);
+    murb_f2 inv;
+    inv.x = __builtin_amdgcn_rsqf(r2.x);
+    inv.y = __builtin_amdgcn_rsqf(r2.y);
+    phi = __builtin_elementwise_fma(gj, inv, phi);
+}
+
 // Variant tags (template parameter MODE)
-#define MURB_MODE_PK_LDS 1      // packed math, j tiles staged in LDS            (default)
+#define MURB_MODE_PK_LDS 1      // packed math, j tiles staged in LDS
 #define MURB_MODE_PK_DIRECT 2   // packed math, j read straight from L2/HBM per wave
 #define MURB_MODE_SC_LDS 3      // scalar math, j tiles staged in LDS
+#define MURB_MODE_PHI 4         // potential instead of acceleration (x component of the output), LDS tiles
 
 // ---- force kernel --------------------------------------------------------------------------------
 // grid.x = i groups of WAVES*R bodies, grid.y = j chunks.  LDS: STAGE layout tiles (8 KiB each).
@@ -187,6 +205,10 @@ __global__ __launch_bounds__(WAVES * 64) void murb_force_kernel(const MurbForceA
 #pragma unroll
                         for (int r = 0; r < R; ++r)
                             murb_interact_pk(xj, yj, zj, gj, xi[r], yi[r], zi[r], soft2, ax[r], ay[r], az[r]);
+                    } else if (MODE == MURB_MODE_PHI) {
+                        const murb_f2 xj = {A.x, A.y}, yj = {A.z, A.w}, zj = {B.x, B.y}, gj = {B.z, B.w};
+#pragma unroll
+                        for (int r = 0; r < R; ++r) murb_interact_phi(xj, yj, zj, gj, xi[r], yi[r], zi[r], soft2, ax[r]);
                     } else {
 #pragma unroll
                         for (int r = 0; r < R; ++r) {

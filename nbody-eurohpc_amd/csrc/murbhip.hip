@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -144,6 +145,7 @@ struct murbhip_ctx {
     int exchange = 0;          // 0 peer copies, 1 RCCL
     bool rank_mode = false;    // one shard here, the others live in other processes
     std::vector<Shard> shards;
+    std::vector<float> host_mass;   // masses as uploaded (energy diagnostic)
     int cur = 0;               // record buffer holding the current positions
     bool uploaded = false;
     bool gather_pending = false;   // an exchange into rec[cur] is in flight on the comm streams
@@ -152,6 +154,7 @@ struct murbhip_ctx {
     int force_exchange = 0;   // run the exchange even with one rank (self-test of the RCCL binding)
     // facts
     int cu_count = 0, clock_mhz = 0;
+    size_t device_mem = 0;     // bytes of HBM on the first device
     int last_parts = 0;
     double interactions_per_launch = 0;
     int async_error = 0;
@@ -167,6 +170,8 @@ struct Plan {
     int split;                       // its i-side sub-blocks per block (1, 2, 4)
     MurbSchedule sched[2];           // [0] own slice (or everything), [1] the rest
 };
+
+constexpr int kPotentialKernel = 100;   // not a selectable variant: murbhip_energy's potential sweep
 
 template <int MODE, int R, int WAVES, int STAGE>
 int launch_force_t(const MurbForceArgs& a, int i_slots, hipStream_t s)
@@ -186,6 +191,7 @@ int launch_force(int variant, const MurbForceArgs& a, int i_slots, hipStream_t s
         case 4: return launch_force_t<MURB_MODE_SC_LDS, 8, 4, 4>(a, i_slots, s);
         case 5: return launch_force_t<MURB_MODE_PK_LDS, 16, 4, 4>(a, i_slots, s);
         case 6: return launch_force_t<MURB_MODE_PK_DIRECT, 4, 4, 1>(a, i_slots, s);
+        case kPotentialKernel: return launch_force_t<MURB_MODE_PHI, 8, 4, 4>(a, i_slots, s);
         default: return MURBHIP_E_INVALID;
     }
 }
@@ -255,24 +261,32 @@ int auto_parts(const murbhip_ctx* c, int variant, unsigned long i_slots, unsigne
     return (int)std::min<unsigned long>(parts, kMaxParts / 2);
 }
 
+// Block pairs a rank evaluates under the (half-ring) pair-symmetric schedule with whole-block items.
+long sym_items_per_rank(const murbhip_ctx* c)
+{
+    const long tb = (long)(c->slice / MURB_SYM_BLOCK), w = c->world;
+    return tb * (tb + 1) / 2 + ((w - 1) / 2) * tb * tb + (w > 1 && w % 2 == 0 ? tb * ((tb + 1) / 2) : 0);
+}
+
+// Bytes of the partial-sum planes of the pair-symmetric kernel (per rank).
+size_t sym_plane_bytes(const murbhip_ctx* c, int split)
+{
+    return (size_t)3 * split * (c->slots / MURB_SYM_BLOCK) * c->slots * sizeof(float);
+}
+
 Plan make_plan(const murbhip_ctx* c)
 {
     Plan p{};
-    // variant 0 = auto: pair-symmetric on one GPU when there are enough block pairs, else one-sided
-    p.variant = (c->variant >= 1 && c->variant <= kNumVariants)
-                    ? c->variant
-                    : ((c->world == 1 && c->n >= kSymmetricMinBodies) ? kSymmetricVariant : kOneSidedVariant);
-    if (c->variant == 0 && c->world > 1) {
-        // half-ring pair-symmetric schedule when every rank gets enough block pairs to fill its GPU
-        const long tb = (long)(c->slice / MURB_SYM_BLOCK), w = c->world;
-        const long items = tb * (tb + 1) / 2 + ((w - 1) / 2) * tb * tb + (w % 2 == 0 ? tb * ((tb + 1) / 2) : 0);
-        p.variant = items >= 400 ? kSymmetricVariant : kOneSidedVariant;
-    }
+    // variant 0 = auto: pair-symmetric when a GPU gets enough block pairs and its partial-sum planes fit
+    // comfortably (they grow as N^2/1024: 0.5 GB at 200k, 12 GB at 1M), else one-sided
+    const bool planes_fit = c->device_mem == 0 || sym_plane_bytes(c, 1) < c->device_mem / 2;
+    if (c->variant >= 1 && c->variant <= kNumVariants) p.variant = c->variant;
+    else if (c->world == 1) p.variant = (c->n >= kSymmetricMinBodies && planes_fit) ? kSymmetricVariant : kOneSidedVariant;
+    else p.variant = (sym_items_per_rank(c) >= 400 && planes_fit) ? kSymmetricVariant : kOneSidedVariant;
     p.symmetric = p.variant == kSymmetricVariant;
     if (p.symmetric) {
-        // finer items (i side cut in 2 or 4) until a rank has ~16 scheduling rounds of them
-        const long tb = (long)(c->slice / MURB_SYM_BLOCK), w = c->world;
-        const long items = tb * (tb + 1) / 2 + ((w - 1) / 2) * tb * tb + (w % 2 == 0 && w > 1 ? tb * ((tb + 1) / 2) : 0);
+        // finer items (i side cut in 2 or 4) until a rank has ~8 scheduling rounds of them
+        const long items = sym_items_per_rank(c);
         const long want = 8L * 4 * std::max(c->cu_count, 1);
         p.split = (c->jsplit == 1 || c->jsplit == 2 || c->jsplit == 4 || c->jsplit == 8 || c->jsplit == 16)
                       ? c->jsplit
@@ -531,7 +545,7 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split)
         sh.bytes += chunk * (W + 1);
     }
     // cells nobody writes must read as 0 in the row sums: zero once per layout, they stay zero
-    const size_t bytes = (size_t)3 * split * (c->slots / MURB_SYM_BLOCK) * c->slots * sizeof(float);
+    const size_t bytes = sym_plane_bytes(c, split);
     if (sh.sym_part) { hipFree(sh.sym_part); sh.sym_part = nullptr; }
     HIP_TRY(hipMalloc((void**)&sh.sym_part, bytes));
     HIP_TRY(hipMemsetAsync(sh.sym_part, 0, bytes, sh.compute));   // on OUR stream: it is non-blocking w.r.t. stream 0
@@ -688,7 +702,7 @@ int create_common(murbhip_ctx** out, unsigned long n, float soft, float g, int w
 
     hipDeviceProp_t prop;
     int rc = hip_rc(hipGetDeviceProperties(&prop, devices[0]));
-    if (rc == 0) { c->cu_count = prop.multiProcessorCount; c->clock_mhz = prop.clockRate / 1000; }
+    if (rc == 0) { c->cu_count = prop.multiProcessorCount; c->clock_mhz = prop.clockRate / 1000; c->device_mem = prop.totalGlobalMem; }
 
     for (int i = 0; rc == 0 && i < nlocal; ++i) {
         Shard& sh = c->shards[i];
@@ -906,6 +920,7 @@ int murbhip_upload(murbhip_ctx* c, const float* qx, const float* qy, const float
         HIP_TRY(hipMemcpy(sh.vel, vel.data(), vel.size() * sizeof(float4), hipMemcpyHostToDevice));
         sh.prof_used = 0;
     }
+    c->host_mass.assign(m, m + c->n);
     c->cur = 0;
     c->gather_pending = false;
     c->uploaded = true;
@@ -1025,6 +1040,44 @@ int murbhip_integrate_host_acc(murbhip_ctx* c, const float* ax, const float* ay,
     }
     if (c->world > 1) RC_TRY(enqueue_exchange(c, c->cur ^ 1));
     c->cur ^= 1;
+    return 0;
+}
+
+int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
+{
+    if (!c || !kinetic || !potential) return MURBHIP_E_INVALID;
+    if (!c->uploaded) return MURBHIP_E_STATE;
+    // phi_i = sum_j GM_j / sqrt(r_ij^2 + soft^2) over ALL j (self term included) with the one-sided
+    // sweep, written to the x plane of the acceleration output
+    Plan p{};
+    p.variant = kPotentialKernel;
+    {
+        const unsigned long tiles_local = c->slice / MURB_TILE_BODIES, tiles_remote = (c->slots - c->slice) / MURB_TILE_BODIES;
+        p.parts_local = std::max(1, auto_parts(c, 1, c->slice, tiles_local));
+        p.parts_remote = c->world > 1 ? std::max(1, std::min<int>(auto_parts(c, 1, c->slice, tiles_remote), kMaxParts / 2)) : 0;
+    }
+    for (Shard& sh : c->shards) {
+        HIP_TRY(hipSetDevice(sh.device));
+        if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
+        RC_TRY(enqueue_force(c, sh, p, 0));
+        if (c->world > 1) RC_TRY(enqueue_force(c, sh, p, 1));
+        RC_TRY(enqueue_integrate(c, sh, p.parts_local + p.parts_remote, 0.f, 0));
+    }
+    std::vector<float> phi(c->n), unused(c->n), vx(c->n), vy(c->n), vz(c->n);
+    RC_TRY(murbhip_download_acc(c, phi.data(), unused.data(), unused.data()));
+    RC_TRY(murbhip_download_state(c, nullptr, nullptr, nullptr, vx.data(), vy.data(), vz.data()));
+    // O(N) part on the host in fp64, with the reference's definitions
+    // (SimulationNBodyCUDAPropertyTracking.cu:287-294: self term removed, both halved)
+    const double soft = std::sqrt((double)c->soft2), G = (double)c->g;
+    double ke = 0.0, pe = 0.0;
+    for (Shard& sh : c->shards)
+        for (unsigned long i = sh.first; i < sh.first + sh.count; ++i) {
+            const double m = c->host_mass[i];
+            ke += 0.5 * m * ((double)vx[i] * vx[i] + (double)vy[i] * vy[i] + (double)vz[i] * vz[i]);
+            pe -= 0.5 * m * ((double)phi[i] - G * m / soft);
+        }
+    *kinetic = ke;
+    *potential = pe;
     return 0;
 }
 

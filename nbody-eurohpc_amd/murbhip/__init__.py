@@ -59,6 +59,7 @@ def lib():
         L.murbhip_steps.argtypes = [C.c_void_p, C.c_float, C.c_int]
         L.murbhip_integrate_host_acc.argtypes = [C.c_void_p] + [_fp] * 3 + [C.c_float]
         L.murbhip_sync.argtypes = [C.c_void_p]
+        L.murbhip_energy.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.murbhip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
         L.murbhip_get_info.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
         _lib = L
@@ -68,7 +69,7 @@ def lib():
 EXPORTS = ("murbhip_version murbhip_error_string murbhip_partition murbhip_slice_slots murbhip_slot_of_body "
            "murbhip_device_count murbhip_create murbhip_create_sharded murbhip_unique_id murbhip_create_rank "
            "murbhip_destroy murbhip_upload murbhip_download_state murbhip_download_acc murbhip_compute_acc "
-           "murbhip_step murbhip_steps murbhip_integrate_host_acc murbhip_sync murbhip_set_option "
+           "murbhip_step murbhip_steps murbhip_integrate_host_acc murbhip_sync murbhip_energy murbhip_set_option "
            "murbhip_get_info").split()
 
 
@@ -169,6 +170,12 @@ class Simulation:
 
     def sync(self):
         _check(lib().murbhip_sync(self._h), "murbhip_sync")
+
+    def energy(self):
+        """(kinetic, potential) of the current state, reference definitions (gpu+tracking)."""
+        ke, pe = C.c_double(), C.c_double()
+        _check(lib().murbhip_energy(self._h, C.byref(ke), C.byref(pe)), "murbhip_energy")
+        return ke.value, pe.value
 
     # -- tuning / facts
     def set_option(self, key, value):

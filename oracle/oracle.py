@@ -61,8 +61,18 @@ def lib():
         L.oracle_accel_f64.argtypes = [C.c_ulong, C.c_ulong, C.c_ulong, _f, _f, _f, _f, C.c_float, _d, _d, _d]
         L.oracle_accel_f64_subset.restype = None
         L.oracle_accel_f64_subset.argtypes = [C.c_ulong, C.c_ulong, _ul, _f, _f, _f, _f, C.c_float, _d, _d, _d]
+        L.oracle_energy_f64.restype = None
+        L.oracle_energy_f64.argtypes = [C.c_ulong] + [_f] * 7 + [C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L
     return _lib
+
+
+def energy_f64(s, soft=SOFT):
+    """(kinetic, potential) in fp64, definitions of the reference's gpu+tracking metric."""
+    ke, pe = C.c_double(), C.c_double()
+    lib().oracle_energy_f64(len(s["qx"]), s["qx"], s["qy"], s["qz"], s["vx"], s["vy"], s["vz"], s["m"], soft,
+                            C.byref(ke), C.byref(pe))
+    return ke.value, pe.value
 
 
 # ----------------------------------------------------------------------------- restated reference path

@@ -54,4 +54,27 @@ void oracle_accel_f64_subset(unsigned long n, unsigned long nsub, const unsigned
     }
 }
 
+// Mechanical energy with the reference's definitions (SimulationNBodyCUDAPropertyTracking.cu:217-304):
+// kinetic = sum 1/2 m v^2, potential = -1/2 sum_i sum_{j != i} G m_i m_j / sqrt(r_ij^2 + soft^2).
+void oracle_energy_f64(unsigned long n, const float* qx, const float* qy, const float* qz, const float* vx,
+                       const float* vy, const float* vz, const float* m, float soft, double* kinetic, double* potential)
+{
+    const double G = (double)6.67384e-11f;
+    const double soft2 = (double)soft * (double)soft;
+    double ke = 0.0, pe = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : ke, pe)
+    for (unsigned long i = 0; i < n; ++i) {
+        ke += 0.5 * (double)m[i] * ((double)vx[i] * vx[i] + (double)vy[i] * vy[i] + (double)vz[i] * vz[i]);
+        double phi = 0.0;
+        for (unsigned long j = 0; j < n; ++j) {
+            if (j == i) continue;
+            const double dx = (double)qx[j] - qx[i], dy = (double)qy[j] - qy[i], dz = (double)qz[j] - qz[i];
+            phi += G * (double)m[j] / std::sqrt(dx * dx + dy * dy + dz * dz + soft2);
+        }
+        pe -= 0.5 * (double)m[i] * phi;
+    }
+    *kinetic = ke;
+    *potential = pe;
+}
+
 }  // extern "C"

@@ -298,6 +298,37 @@ def test_rccl_binding_single_rank(gpu, O):
             np.testing.assert_allclose(b[k], a[k], rtol=TOL_POS, atol=1.0)
 
 
+@pytest.mark.parametrize("scheme,n", [("galaxy", 5000), ("random", 3001), ("galaxy", 30000)])
+def test_energy_metric(gpu, O, scheme, n):
+    """the energy metric of the reference's gpu+tracking implementation
+    (SimulationNBodyCUDAPropertyTracking.cu:217-304) against an fp64 evaluation, before and after
+    stepping.  The reference's integrator is not symplectic: over 10 steps of an hour the galaxy drifts
+    by ~3e-4 of its energy, on the GPU exactly as on the cpu+optim trajectory."""
+    s = O.init_bodies(n, scheme)
+    ke0, pe0 = O.energy_f64(s, SOFT)
+    with gpu.Simulation(n, soft=SOFT) as sim:
+        sim.upload(s)
+        ke, pe = sim.energy()
+        assert abs(ke - ke0) <= 1e-6 * abs(ke0) and abs(pe - pe0) <= 2e-6 * abs(pe0)
+        sim.steps(DT, 10)
+        ke1, pe1 = sim.energy()
+        st = sim.state()
+    st["m"] = s["m"]
+    ke2, pe2 = O.energy_f64(st, SOFT)
+    assert abs(ke1 - ke2) <= 1e-6 * abs(ke2) and abs(pe1 - pe2) <= 2e-6 * abs(pe2)
+    assert abs((ke1 + pe1) - (ke0 + pe0)) <= 2e-3 * abs(ke0 + pe0)
+    if n <= 5000:   # same drift as the reference's own CPU trajectory
+        ref = {k: v.copy() for k, v in s.items()}
+        O.simulate(ref, 10, "cpu+optim", SOFT, DT)
+        ke4, pe4 = O.energy_f64(ref, SOFT)
+        assert abs((ke1 + pe1) - (ke4 + pe4)) <= 2e-6 * abs(ke4 + pe4)
+    # sharded: every shard evaluates its own bodies against all positions
+    with gpu.Simulation(n, soft=SOFT, devices=[0, 0, 0]) as many:
+        many.upload(s)
+        ke3, pe3 = many.energy()
+        assert abs(ke3 - ke0) <= 1e-6 * abs(ke0) and abs(pe3 - pe0) <= 2e-6 * abs(pe0)
+
+
 def test_errors_are_reported(gpu):
     with gpu.Simulation(100, soft=SOFT) as sim:
         with pytest.raises(gpu.MurbHipError):
