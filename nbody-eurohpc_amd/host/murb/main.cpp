@@ -36,56 +36,75 @@ bool ShowGFlops = false;
 int NDevices = 0;        // --ngpu, hip+tile+multi only (0 = all visible)
 bool FreeRunning = false;   // --free: sync once at the end instead of once per iteration
 
+// One row per command-line option: tag (as Arguments_reader wants it: "-im" is typed "--im"), name of
+// its value ("" = flag), required?, help text.  Same options as the reference (main.cpp:66-112) minus
+// OpenCL's, plus --ngpu and --free.
+struct Option {
+    const char *tag, *value;
+    bool required;
+    std::string help;
+};
+
+static std::vector<Option> optionTable()
+{
+    return {
+        {"n", "nBodies", true, "the number of generated bodies."},
+        {"i", "nIterations", true, "the number of iterations to compute."},
+        {"v", "", false, "enable verbose mode."},
+        {"h", "", false, "display this help."},
+        {"-help", "", false, "display this help."},
+        {"-dt", "timeStep", false, "select a fixed time step in second (default is " + std::to_string(Dt) + " sec)."},
+        {"-ngs", "", false, "accepted for compatibility (no visualization in this driver)."},
+        {"-nv", "", false, "no visualization (always the case here)."},
+        {"-nvc", "", false, "accepted for compatibility."},
+        {"-ww", "winWidth", false, "accepted for compatibility."},
+        {"-wh", "winHeight", false, "accepted for compatibility."},
+        {"-im", "ImplTag", false,
+         "code implementation tag:\n"
+         "\t\t\t - \"hip+tile\"        one MI355X, device-resident bodies\n"
+         "\t\t\t - \"hip+tile+multi\"  bodies partitioned over --ngpu MI355X, RCCL position exchange\n"
+         "\t\t\t ----"},
+        {"-soft", "softeningFactor", false, "softening factor."},
+        {"s", "bodies scheme", false, "bodies scheme (initial conditions can be \"galaxy\" or \"random\")."},
+        {"-gf", "", false, "display the number of GFlop/s."},
+        {"-ngpu", "nGpus", false, "number of GPUs for hip+tile+multi (default: all visible)."},
+        {"-free", "", false, "free-running timing: one device sync at the end, not one per iteration."},
+    };
+}
+
 static void argsReader(int argc, char **argv)
 {
     std::map<std::string, std::string> reqArgs, faculArgs, docArgs;
+    for (const Option &o : optionTable()) {
+        (o.required ? reqArgs : faculArgs)[o.tag] = o.value;
+        docArgs[o.tag] = o.help;
+    }
     Arguments_reader reader(argc, argv);
-    reqArgs["n"] = "nBodies";          docArgs["n"] = "the number of generated bodies.";
-    reqArgs["i"] = "nIterations";      docArgs["i"] = "the number of iterations to compute.";
-    faculArgs["v"] = "";               docArgs["v"] = "enable verbose mode.";
-    faculArgs["h"] = "";               docArgs["h"] = "display this help.";
-    faculArgs["-help"] = "";           docArgs["-help"] = "display this help.";
-    faculArgs["-dt"] = "timeStep";     docArgs["-dt"] = "select a fixed time step in second (default is " + std::to_string(Dt) + " sec).";
-    faculArgs["-ngs"] = "";            docArgs["-ngs"] = "accepted for compatibility (no visualization in this driver).";
-    faculArgs["-nv"] = "";             docArgs["-nv"] = "no visualization (always the case here).";
-    faculArgs["-nvc"] = "";            docArgs["-nvc"] = "accepted for compatibility.";
-    faculArgs["-ww"] = "winWidth";     docArgs["-ww"] = "accepted for compatibility.";
-    faculArgs["-wh"] = "winHeight";    docArgs["-wh"] = "accepted for compatibility.";
-    faculArgs["-im"] = "ImplTag";
-    docArgs["-im"] = "code implementation tag:\n"
-                     "\t\t\t - \"hip+tile\"        one MI355X, device-resident bodies\n"
-                     "\t\t\t - \"hip+tile+multi\"  bodies partitioned over --ngpu MI355X, RCCL position exchange\n"
-                     "\t\t\t ----";
-    faculArgs["-soft"] = "softeningFactor"; docArgs["-soft"] = "softening factor.";
-    faculArgs["s"] = "bodies scheme";  docArgs["s"] = "bodies scheme (initial conditions can be \"galaxy\" or \"random\").";
-    faculArgs["-gf"] = "";             docArgs["-gf"] = "display the number of GFlop/s.";
-    faculArgs["-ngpu"] = "nGpus";      docArgs["-ngpu"] = "number of GPUs for hip+tile+multi (default: all visible).";
-    faculArgs["-free"] = "";           docArgs["-free"] = "free-running timing: one device sync at the end, not one per iteration.";
-
-    const bool ok = reader.parse_arguments(reqArgs, faculArgs);
-    if (!ok || reader.exist_argument("h") || reader.exist_argument("-help")) {
+    const bool complete = reader.parse_arguments(reqArgs, faculArgs);
+    if (!complete || reader.exist_argument("h") || reader.exist_argument("-help")) {
         if (reader.parse_doc_args(docArgs)) reader.print_usage();
         else std::cout << "A problem was encountered when parsing arguments documentation... exiting." << std::endl;
         exit(-1);
     }
+    const auto given = [&](const char *tag) { return reader.exist_argument(tag); };
     NBodies = stoi(reader.get_argument("n"));
     NIterations = stoi(reader.get_argument("i"));
-    if (reader.exist_argument("v")) Verbose = true;
-    if (reader.exist_argument("-dt")) Dt = stof(reader.get_argument("-dt"));
-    if (reader.exist_argument("-ngs")) GSEnable = false;
-    if (reader.exist_argument("-nv")) VisuEnable = false;
-    if (reader.exist_argument("-im")) ImplTag = reader.get_argument("-im");
-    if (reader.exist_argument("-soft")) {
+    Verbose = given("v");
+    GSEnable = !given("-ngs");
+    VisuEnable = !given("-nv");
+    ShowGFlops = given("-gf");
+    FreeRunning = given("-free");
+    if (given("-dt")) Dt = stof(reader.get_argument("-dt"));
+    if (given("-im")) ImplTag = reader.get_argument("-im");
+    if (given("s")) BodiesScheme = reader.get_argument("s");
+    if (given("-ngpu")) NDevices = stoi(reader.get_argument("-ngpu"));
+    if (given("-soft")) {
         Softening = stof(reader.get_argument("-soft"));
-        if (Softening == 0.f) {
+        if (Softening == 0.f) {   // the reference refuses it too (main.cpp:147-150): the self term would be 0/0
             std::cout << "Softening factor can't be equal to 0... exiting." << std::endl;
             exit(-1);
         }
     }
-    if (reader.exist_argument("s")) BodiesScheme = reader.get_argument("s");
-    if (reader.exist_argument("-gf")) ShowGFlops = true;
-    if (reader.exist_argument("-ngpu")) NDevices = stoi(reader.get_argument("-ngpu"));
-    if (reader.exist_argument("-free")) FreeRunning = true;
 }
 
 // "..d ..h ..m ..s" (main.cpp:175-196)
