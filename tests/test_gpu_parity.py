@@ -458,3 +458,29 @@ def test_murb_hip_cli_output(gpu):
     ms, fps, gf = float(m.group(1)), float(m.group(2)), float(m.group(3))
     assert abs(fps - 20 * 1000.0 / ms) / fps < 1e-2
     assert abs(gf - 20.0 * 30000.0 ** 2 * fps / 1024 ** 3) / gf < 2e-2       # Perf.cpp:28 definition
+
+
+def test_bench_contract(gpu):
+    """bench.py prints exactly ONE JSON line on stdout with the contract's keys (small run)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "30000", "--steps", "20", "--warmup", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["metric"] == "body-interactions/s" and d["n_gpus"] == 1 and d["steps"] == 20 and d["dtype"] == "f32"
+    assert d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 30000.0 ** 2 * 20 / (d["ms_per_step"] * 20e-3)) / d["value"] < 1e-6
+    roof = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in roof, k
+    assert roof["unit"] == "TFLOP/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert 0.05 < roof["frac"] < 1.0 and d["value"] > 1e12
+    assert d["parity"]["max_rel"] <= d["parity"]["tolerance_max_rel"]
