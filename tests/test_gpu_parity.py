@@ -171,6 +171,27 @@ def test_variants_and_jsplit_agree(gpu, O):
     assert all(np.array_equal(bits(x), bits(y)) for x, y in zip(base, again))
 
 
+@pytest.mark.parametrize("soft", [1e3, 1e6, 1e7, 1e10])
+@pytest.mark.parametrize("variant", [1, 8])
+def test_other_softening_lengths(gpu, O, soft, variant):
+    """--soft is a CLI parameter of the reference (main.cpp:111,144-151): small values make close pairs
+    dominate (and fp32 differences of 1e8-sized coordinates noisy for every implementation), large ones
+    flatten the field.  The GPU must stay as close to the fp64 truth as cpu+optim does."""
+    n = 3000
+    s = O.init_bodies(n, "galaxy")
+    soft = np.float32(soft)
+    truth = O.accel_f64(s, soft)
+    opt_err = O.rel_err(O.accel_optim(s, soft), truth).max()
+    with gpu.Simulation(n, soft=soft) as sim:
+        sim.set_option("variant", variant)
+        sim.upload(s)
+        sim.compute_acc()
+        sim.sync()
+        a = sim.acc()
+    assert all(np.isfinite(c).all() for c in a)
+    assert O.rel_err(a, truth).max() <= max(TOL_F64_MAX, 2.0 * opt_err)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 63, 513])
 def test_tiny_and_ragged_sizes(gpu, O, n):
     s = O.init_bodies(n, "random")
@@ -327,6 +348,33 @@ def test_energy_metric(gpu, O, scheme, n):
         many.upload(s)
         ke3, pe3 = many.energy()
         assert abs(ke3 - ke0) <= 1e-6 * abs(ke0) and abs(pe3 - pe0) <= 2e-6 * abs(pe0)
+
+
+def test_long_run_stays_on_the_reference_trajectory(gpu, O):
+    """200 iterations (the benchmark's -i 200) at N = 2048: positions still agree with cpu+optim to 1e-5,
+    the energy drifts like the reference's, momentum is conserved, state survives re-upload."""
+    n = 2048
+    s = O.init_bodies(n, "galaxy")
+    ref = {k: v.copy() for k, v in s.items()}
+    O.simulate(ref, 200, "cpu+optim", SOFT, DT)
+    with gpu.Simulation(n, soft=SOFT) as sim:
+        sim.upload(s)
+        sim.steps(DT, 120)
+        mid = sim.state()          # download in the middle of a run, then continue from a fresh upload
+        mid["m"] = s["m"]
+        sim.upload(mid)
+        sim.steps(DT, 80)
+        st = sim.state()
+        ke, pe = sim.energy()
+    for k in ("qx", "qy", "qz"):
+        np.testing.assert_allclose(st[k], ref[k], rtol=1e-5, atol=1.0e3)   # 1e-5 of the 1e8 m scale
+    ke_r, pe_r = O.energy_f64(ref, SOFT)
+    assert abs((ke + pe) - (ke_r + pe_r)) <= 1e-5 * abs(ke_r + pe_r)
+    m = s["m"].astype(np.float64)
+    p0 = np.array([(m * s[k].astype(np.float64)).sum() for k in ("vx", "vy", "vz")])
+    p1 = np.array([(m * st[k].astype(np.float64)).sum() for k in ("vx", "vy", "vz")])
+    scale = (m * np.abs(st["vx"].astype(np.float64))).sum()
+    assert np.abs(p1 - p0).max() <= 1e-5 * scale
 
 
 def test_errors_are_reported(gpu):
