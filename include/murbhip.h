@@ -136,7 +136,8 @@ int murbhip_sync(murbhip_ctx* ctx);
  * G m_i m_j / sqrt(r_ij^2 + soft^2) — the per-iteration metric of the reference's gpu+tracking
  * implementation (SimulationNBodyCUDAPropertyTracking.cu:217-304, summed there with cub).  One N^2
  * potential sweep on the device, the O(N) sum in fp64 on the host; waits for enqueued steps.  In rank
- * mode the values cover the caller's own bodies only (sum them over ranks). */
+ * mode the values cover the caller's own bodies only (sum them over ranks).  The potential sweep reuses
+ * the acceleration output: murbhip_download_acc() returns it (x plane) until the next step. */
 int murbhip_energy(murbhip_ctx* ctx, double* kinetic, double* potential);
 
 /* ------------------------------------------------------------------ tuning and measurement */
