@@ -514,7 +514,7 @@ def test_bench_contract(gpu):
     import subprocess
     import sys
     from conftest import ROOT
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "30000", "--steps", "20", "--warmup", "2",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--bodies", "30000", "--steps", "20", "--warmup", "2",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
