@@ -390,9 +390,9 @@ def test_errors_are_reported(gpu):
 
 
 # ---- BASELINE.json sizes: size-independent properties -------------------------------------------
-@pytest.mark.parametrize("n", [30000, 200000, 1000000])
-def test_full_size_properties(gpu, O, n):
-    s = O.init_bodies(n, "galaxy")
+@pytest.mark.parametrize("n,scheme", [(30000, "galaxy"), (200000, "galaxy"), (200000, "random"), (1000000, "galaxy")])
+def test_full_size_properties(gpu, O, n, scheme):
+    s = O.init_bodies(n, scheme)
     with gpu.Simulation(n, soft=SOFT) as sim:
         sim.upload(s)
         sim.compute_acc()
