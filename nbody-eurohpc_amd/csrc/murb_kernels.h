@@ -365,7 +365,8 @@ struct MurbIntegrateArgs {
     unsigned int acc_stride;
     float dt;
     int update_state;        // 0: only reduce partial sums into acc_out
-    const float* acc_planes; // complete accelerations ax | ay | az (acc_stride each), e.g. after a reduce-scatter
+    const float* acc_planes; // accelerations ax | ay | az (acc_stride each): row sums, or a reduce-scatter's output
+    const float* acc_planes2;// optional second addend of the same shape (own-slice part that skipped the reduce-scatter)
     int nsched;              // persistent launches that produced accp (0, 1 or 2)
     int group_bodies;        // bodies per i group of those launches
     MurbSchedule sched[2];
@@ -407,6 +408,11 @@ __global__ __launch_bounds__(256) void murb_integrate_kernel(const MurbIntegrate
         acc0.x = a.acc_planes[s0]; acc1.x = a.acc_planes[s0 + 1];
         acc0.y = a.acc_planes[a.acc_stride + s0]; acc1.y = a.acc_planes[a.acc_stride + s0 + 1];
         acc0.z = a.acc_planes[2u * a.acc_stride + s0]; acc1.z = a.acc_planes[2u * a.acc_stride + s0 + 1];
+        if (a.acc_planes2) {
+            acc0.x += a.acc_planes2[s0]; acc1.x += a.acc_planes2[s0 + 1];
+            acc0.y += a.acc_planes2[a.acc_stride + s0]; acc1.y += a.acc_planes2[a.acc_stride + s0 + 1];
+            acc0.z += a.acc_planes2[2u * a.acc_stride + s0]; acc1.z += a.acc_planes2[2u * a.acc_stride + s0 + 1];
+        }
     } else if (a.nsched == 0) {
         for (int p = 0; p < a.nparts; ++p) {
             const float4 u = a.accp[(unsigned long)p * a.acc_stride + s0];

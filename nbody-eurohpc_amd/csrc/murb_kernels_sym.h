@@ -42,6 +42,8 @@ struct MurbSymArgs {
                            // the j side is block J; block(Isub) = Isub / split <= J, equal = diagonal item
     int item_first;        // first entry of `items` this launch evaluates
     int split;             // sub-blocks per block on the i side: 1, 2 or 4 (finer items for small problems)
+    int plane_block0;      // block index that row 0 / slot 0 of `part` corresponds to (0 for planes that span
+                           // the whole record buffer; a rank's first block for its own-slice-only planes)
     int nrows;             // rows per plane = split * (blocks in the record buffer)
     unsigned int row_stride;   // floats per row (= slots of the record buffer)
     float soft2;
@@ -155,14 +157,16 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
     const bool diagonal = (I / split) == J;
     const int groups_per_wave = MURB_SYM_BLOCK / R / 4 / split;      // 64, 32 or 16
     const unsigned int i_block_slot = (unsigned int)I * (unsigned int)(MURB_SYM_BLOCK / split);
-    const unsigned int i_local_slot = i_block_slot;
+    // the same item in the coordinates of the partial-sum planes
+    const int Ip = I - a.plane_block0 * split, Jp = J - a.plane_block0;
+    const unsigned int i_local_slot = (unsigned int)Ip * (unsigned int)(MURB_SYM_BLOCK / split);
     // where this lane's i-side total goes: value idx(lane) = 3 * body + component (see murb_reduce12)
     unsigned long out_off;
     {
         const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
         const int idx = b2 ? 8 + 2 * b4 + b5 : 4 * b3 + 2 * b4 + b5;
         const int r = idx / 3, c = idx - 3 * r;
-        out_off = ((unsigned long)c * a.nrows + (unsigned long)split * J) * a.row_stride + i_local_slot + r;
+        out_off = ((unsigned long)c * a.nrows + (unsigned long)split * Jp) * a.row_stride + i_local_slot + r;
     }
 #pragma unroll 1
     for (int gk = 0; gk < groups_per_wave; ++gk) {
@@ -250,10 +254,10 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
         }
         __syncthreads();
         if (wave == 0) {
-            const unsigned long base = (unsigned long)J * MURB_SYM_BLOCK;
-            murb_f2* px = reinterpret_cast<murb_f2*>(a.part + ((unsigned long)0 * a.nrows + I) * a.row_stride + base);
-            murb_f2* py = reinterpret_cast<murb_f2*>(a.part + ((unsigned long)1 * a.nrows + I) * a.row_stride + base);
-            murb_f2* pz = reinterpret_cast<murb_f2*>(a.part + ((unsigned long)2 * a.nrows + I) * a.row_stride + base);
+            const unsigned long base = (unsigned long)Jp * MURB_SYM_BLOCK;
+            murb_f2* px = reinterpret_cast<murb_f2*>(a.part + ((unsigned long)0 * a.nrows + Ip) * a.row_stride + base);
+            murb_f2* py = reinterpret_cast<murb_f2*>(a.part + ((unsigned long)1 * a.nrows + Ip) * a.row_stride + base);
+            murb_f2* pz = reinterpret_cast<murb_f2*>(a.part + ((unsigned long)2 * a.nrows + Ip) * a.row_stride + base);
 #pragma unroll
             for (int p = 0; p < MURB_SYM_STEPS; ++p) {
                 px[p * 64 + lane] = ajx[p] + scratch[0][0][p * 64 + lane];

@@ -121,9 +121,12 @@ struct Shard {
     int2* sym_items = nullptr;
     int sym_items_own = 0, sym_items_total = 0;   // [0, own) = own-slice triangle, the rest need the gathered positions
     int sym_split = 0;                            // i-side sub-blocks per block the table was built for
+    bool sym_exchange_mode = false;               // ... and whether it was built for the exchange pipeline
     MurbSymRowRanges* sym_ranges = nullptr;
     float* sym_send = nullptr;   // [world][3][slice]
     float* sym_recv = nullptr;   // [3][slice]
+    float* sym_tri = nullptr;    // partial planes of the own-slice triangle only: 3 x (split*tb) rows x slice
+    float* sym_tri_acc = nullptr;// their row sums [3][slice]
     hipEvent_t ev_rowsum = nullptr, ev_reduced = nullptr;
     rccl_comm_t comm_rccl = nullptr;
     std::vector<hipEvent_t> prof;   // start/stop pairs around force launches
@@ -149,6 +152,7 @@ struct murbhip_ctx {
     int cur = 0;               // record buffer holding the current positions
     bool uploaded = false;
     bool gather_pending = false;   // an exchange into rec[cur] is in flight on the comm streams
+    bool reduce_pending = false;   // peers may still be reading this context's reduce-scatter send buffers
     // options
     int variant = 0, jsplit = 0, profile = 0, overlap = 1;
     int force_exchange = 0;   // run the exchange even with one rank (self-test of the RCCL binding)
@@ -341,7 +345,7 @@ int prof_end(murbhip_ctx* c, Shard& sh)
 }
 
 int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split);
-int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count);
+int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_planes = false);
 
 // Force over the tiles of `which` (0 = own slice / everything when world == 1, 1 = all but own slice).
 int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
@@ -478,7 +482,8 @@ int enqueue_exchange(murbhip_ctx* c, int buf)
 // rank receives the complete accelerations of its own bodies); positions travel as before.
 int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split)
 {
-    if (sh.sym_items && sh.sym_split == split) return 0;
+    const bool exchange_mode = c->world > 1 || c->force_exchange;
+    if (sh.sym_items && sh.sym_split == split && sh.sym_exchange_mode == exchange_mode) return 0;
     if (sh.sym_items) {   // option changed: rebuild (the planes are re-zeroed because the row meaning changes)
         HIP_TRY(hipStreamSynchronize(sh.compute));
         hipFree(sh.sym_items); sh.sym_items = nullptr;
@@ -496,9 +501,13 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split)
     rr.blocks_per_slice = tb;
     for (int sl = 0; sl < W; ++sl)
         for (int k = 0; k < 3; ++k) rr.stride[sl][k] = 1;
-    // own bodies: all rows of the own slice (j-side cells dense, i-side cells every `split`-th) ...
-    rr.first[r][0] = r * ts;
-    rr.count[r][0] = ts;
+    // Own bodies.  Under an exchange the own-slice triangle has planes of its own (so that its row sum
+    // can run while the reduce-scatter of everything else is in flight); without one (single context)
+    // all rows of the own slice live in the big planes: j-side cells dense, i-side cells every `split`-th
+    if (!exchange_mode) {
+        rr.first[r][0] = r * ts;
+        rr.count[r][0] = ts;
+    }
     // ... and the i-side cells of the rectangles: rows split*J of slices r+1 .. r+W/2 (cyclic, <= 2 ranges)
     const int far = W / 2;
     if (far > 0 && W > 1) {
@@ -532,6 +541,7 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split)
     sh.sym_items_own = own;
     sh.sym_items_total = (int)items.size();
     sh.sym_split = split;
+    sh.sym_exchange_mode = exchange_mode;
     HIP_TRY(hipMalloc((void**)&sh.sym_items, items.size() * sizeof(int2)));
     HIP_TRY(hipMemcpy(sh.sym_items, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice));
     if (!sh.sym_ranges) HIP_TRY(hipMalloc((void**)&sh.sym_ranges, sizeof rr));
@@ -544,6 +554,14 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split)
         HIP_TRY(hipEventCreateWithFlags(&sh.ev_reduced, hipEventDisableTiming));
         sh.bytes += chunk * (W + 1);
     }
+    if (exchange_mode) {
+        const size_t tri_bytes = (size_t)3 * ts * c->slice * sizeof(float);
+        hipFree(sh.sym_tri); sh.sym_tri = nullptr;
+        HIP_TRY(hipMalloc((void**)&sh.sym_tri, tri_bytes));
+        HIP_TRY(hipMemsetAsync(sh.sym_tri, 0, tri_bytes, sh.compute));
+        if (!sh.sym_tri_acc) HIP_TRY(hipMalloc((void**)&sh.sym_tri_acc, chunk));
+        sh.bytes += tri_bytes + chunk;
+    }
     // cells nobody writes must read as 0 in the row sums: zero once per layout, they stay zero
     const size_t bytes = sym_plane_bytes(c, split);
     if (sh.sym_part) { hipFree(sh.sym_part); sh.sym_part = nullptr; }
@@ -553,17 +571,25 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split)
     return 0;
 }
 
-int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count)
+int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_planes)
 {
     if (count <= 0) return 0;
     MurbSymArgs sa{};
     sa.rec = sh.rec[c->cur];
-    sa.part = sh.sym_part;
     sa.items = sh.sym_items;
     sa.item_first = first;
     sa.split = sh.sym_split;
-    sa.nrows = sh.sym_split * (int)(c->slots / MURB_SYM_BLOCK);
-    sa.row_stride = (unsigned int)c->slots;
+    if (own_triangle_planes) {   // planes that cover the rank's own slice only
+        sa.part = sh.sym_tri;
+        sa.plane_block0 = sh.rank * (int)(c->slice / MURB_SYM_BLOCK);
+        sa.nrows = sh.sym_split * (int)(c->slice / MURB_SYM_BLOCK);
+        sa.row_stride = (unsigned int)c->slice;
+    } else {
+        sa.part = sh.sym_part;
+        sa.plane_block0 = 0;
+        sa.nrows = sh.sym_split * (int)(c->slots / MURB_SYM_BLOCK);
+        sa.row_stride = (unsigned int)c->slots;
+    }
     sa.soft2 = c->soft2;
     RC_TRY(prof_begin(c, sh));
     hipLaunchKernelGGL(murb_force_sym_kernel<4>, dim3((unsigned)count), dim3(256), 0, sh.compute, sa);
@@ -572,28 +598,40 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count)
     return 0;
 }
 
+// One iteration under the half-ring schedule.  Per shard, on the compute stream unless noted:
+//   T1  first half of the own-slice triangle          (needs no remote data: overlaps the position gather)
+//       wait: positions of the previous step gathered
+//   R   rectangles against the other slices            -> big planes
+//   SR  row sum of the big planes -> send chunks       (own-slice chunk = i-side sums of the rectangles)
+//       [comm stream] reduce-scatter of the chunks -> recv          (overlaps T2)
+//   T2  second half of the own-slice triangle          -> own-slice planes
+//   ST  row sum of the own-slice planes -> tri_acc
+//       wait: reduce-scatter done
+//   I   integrate with acc = recv + tri_acc ; then [comm stream] all-gather of the new positions
+// The triangle never enters the reduce-scatter (it only touches the rank's own bodies), which is what
+// lets half of it hide the collective's latency.
 int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int update_state)
 {
     const unsigned int chunk_floats = (unsigned int)(3 * c->slice);
+    const int rows_all = (int)(c->slots / MURB_SYM_BLOCK), rows_own = (int)(c->slice / MURB_SYM_BLOCK);
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
         RC_TRY(build_sym_schedule(c, sh, p.split));
-        if (c->overlap) {
-            RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_own));   // own slice: no remote data needed
-            if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
-            RC_TRY(enqueue_sym_launch(c, sh, sh.sym_items_own, sh.sym_items_total - sh.sym_items_own));
-        } else {
-            if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
-            RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_total));
-        }
+        const int own = sh.sym_items_own, t1 = c->overlap ? own / 2 : 0;
+        RC_TRY(enqueue_sym_launch(c, sh, 0, t1, true));
+        if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
+        RC_TRY(enqueue_sym_launch(c, sh, own, sh.sym_items_total - own, false));
+        if (c->exchange == 0 && c->reduce_pending)   // peer-read reduce: nobody may still be reading our send buffer
+            for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.compute, peer.ev_reduced, 0));
         hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slots / 64)), dim3(256), 0, sh.compute,
-                           sh.sym_part, sh.sym_split * (int)(c->slots / MURB_SYM_BLOCK), (unsigned int)c->slots,
-                           sh.sym_ranges, sh.sym_split, sh.sym_send);
+                           sh.sym_part, sh.sym_split * rows_all, (unsigned int)c->slots, sh.sym_ranges, sh.sym_split,
+                           sh.sym_send);
         RC_TRY(hip_rc(hipGetLastError()));
         HIP_TRY(hipEventRecord(sh.ev_rowsum, sh.compute));
         c->interactions_per_launch = (double)sh.count * (double)c->n;
     }
-    // reduce-scatter: every rank ends up with the complete accelerations of its own slice
+    // reduce-scatter on the comm streams: every rank ends up with the other ranks' (and its own
+    // rectangles') contributions to its own bodies
     if (c->exchange == 1) {
         Rccl& r = rccl();
         for (Shard& sh : c->shards) {
@@ -607,26 +645,29 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
                                            sh.comm)));
         }
         RC_TRY(nccl_rc(r.GroupEnd()));
-        for (Shard& sh : c->shards) {
-            HIP_TRY(hipSetDevice(sh.device));
-            HIP_TRY(hipEventRecord(sh.ev_reduced, sh.comm));
-            HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
-        }
     } else {
         MurbPeerPtrs peers{};
         peers.n = (int)c->shards.size();
         for (size_t k = 0; k < c->shards.size(); ++k) peers.p[c->shards[k].rank] = c->shards[k].sym_send;
         for (Shard& sh : c->shards) {
             HIP_TRY(hipSetDevice(sh.device));
-            for (Shard& peer : c->shards)
-                if (&peer != &sh) HIP_TRY(hipStreamWaitEvent(sh.compute, peer.ev_rowsum, 0));
-            hipLaunchKernelGGL(murb_sym_peer_sum_kernel, dim3((chunk_floats + 255) / 256), dim3(256), 0, sh.compute, peers,
+            for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.comm, peer.ev_rowsum, 0));
+            hipLaunchKernelGGL(murb_sym_peer_sum_kernel, dim3((chunk_floats + 255) / 256), dim3(256), 0, sh.comm, peers,
                                (unsigned long)sh.rank * chunk_floats, chunk_floats, sh.sym_recv);
             RC_TRY(hip_rc(hipGetLastError()));
         }
     }
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
+        HIP_TRY(hipEventRecord(sh.ev_reduced, sh.comm));
+        // meanwhile: the rest of the own-slice triangle and its row sum
+        const int own = sh.sym_items_own, t1 = c->overlap ? own / 2 : 0;
+        RC_TRY(enqueue_sym_launch(c, sh, t1, own - t1, true));
+        hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slice / 64)), dim3(256), 0, sh.compute,
+                           sh.sym_tri, sh.sym_split * rows_own, (unsigned int)c->slice,
+                           (const MurbSymRowRanges*)nullptr, sh.sym_split, sh.sym_tri_acc);
+        RC_TRY(hip_rc(hipGetLastError()));
+        HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
         MurbIntegrateArgs a{};
         a.rec_in = sh.rec[c->cur];
         a.rec_out = sh.rec[c->cur ^ 1];
@@ -634,6 +675,7 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
         a.accp = sh.accp;
         a.acc_out = sh.acc_out;
         a.acc_planes = sh.sym_recv;
+        a.acc_planes2 = sh.sym_tri_acc;
         a.i_first_slot = (int)((unsigned long)sh.rank * c->slice);
         a.count = (int)sh.count;
         a.acc_stride = (unsigned int)c->slice;
@@ -642,11 +684,11 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
         hipLaunchKernelGGL(murb_integrate_kernel, dim3((unsigned)((c->slice / 2 + 255) / 256)), dim3(256), 0, sh.compute, a);
         RC_TRY(hip_rc(hipGetLastError()));
     }
+    c->reduce_pending = true;
     if (update_state) {
         RC_TRY(enqueue_exchange(c, c->cur ^ 1));
         c->cur ^= 1;
     }
-    (void)p;
     return 0;
 }
 
@@ -892,6 +934,7 @@ int murbhip_destroy(murbhip_ctx* c)
         if (sh.comm) hipStreamDestroy(sh.comm);
         hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out); hipFree(sh.sym_part);
         hipFree(sh.sym_items); hipFree(sh.sym_ranges); hipFree(sh.sym_send); hipFree(sh.sym_recv);
+        hipFree(sh.sym_tri); hipFree(sh.sym_tri_acc);
         if (sh.ev_rowsum) hipEventDestroy(sh.ev_rowsum);
         if (sh.ev_reduced) hipEventDestroy(sh.ev_reduced);
     }
