@@ -753,7 +753,13 @@ int create_common(murbhip_ctx** out, unsigned long n, float soft, float g, int w
         partition(n, world, sh.rank, &sh.first, &sh.count);
         if ((rc = hip_rc(hipSetDevice(sh.device)))) break;
         if ((rc = hip_rc(hipStreamCreateWithFlags(&sh.compute, hipStreamNonBlocking)))) break;
-        if ((rc = hip_rc(hipStreamCreateWithFlags(&sh.comm, hipStreamNonBlocking)))) break;
+        // the exchange stream gets the highest priority: its (few, small) collective kernels must be
+        // dispatched as soon as they are ready although the force kernel keeps every CU full
+        {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if ((rc = hip_rc(hipStreamCreateWithPriority(&sh.comm, hipStreamNonBlocking, greatest)))) break;
+        }
         if ((rc = hip_rc(hipEventCreateWithFlags(&sh.ev_integrated, hipEventDisableTiming)))) break;
         if ((rc = hip_rc(hipEventCreateWithFlags(&sh.ev_gathered, hipEventDisableTiming)))) break;
         const size_t rec_bytes = c->slots * sizeof(float4);
