@@ -16,6 +16,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "_build", "liboracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libmurbref.so")
+REF_AVX2_SO = os.path.join(HERE, "_ref", "libmurbref_avx2.so")   # same sources + -mavx2 -mfma: speed baseline only
 
 G = np.float32(6.67384e-11)      # SimulationNBodyInterface.hpp:18
 SOFT = np.float32(2e8)           # main.cpp:47
@@ -151,19 +152,19 @@ def rel_err(test, ref):
 
 
 # ----------------------------------------------------------------------------- the real reference (checker only)
-_ref = None
+_ref = {}
 
 
-def have_ref():
-    return os.path.exists(REF_SO)
+def have_ref(avx2=False):
+    return os.path.exists(REF_AVX2_SO if avx2 else REF_SO)
 
 
-def ref_lib():
-    global _ref
-    if _ref is None:
-        if not have_ref():
-            raise FileNotFoundError(REF_SO + " not built (make -C oracle ref needs /root/reference)")
-        L = C.CDLL(REF_SO)
+def ref_lib(avx2=False):
+    path = REF_AVX2_SO if avx2 else REF_SO
+    if path not in _ref:
+        if not os.path.exists(path):
+            raise FileNotFoundError(path + " not built (make -C oracle ref needs /root/reference)")
+        L = C.CDLL(path)
         L.murbref_create.restype = C.c_void_p
         L.murbref_create.argtypes = [C.c_char_p, C.c_ulong, C.c_char_p, C.c_float, C.c_float]
         L.murbref_destroy.argtypes = [C.c_void_p]
@@ -180,15 +181,15 @@ def ref_lib():
         L.murbref_get_acc.restype = C.c_int
         L.murbref_get_acc.argtypes = [C.c_void_p, _f, _f, _f]
         L.murbref_integrate.argtypes = [C.c_ulong, C.c_char_p, _f, _f, _f, C.c_float, C.c_int] + [_f] * 6
-        _ref = L
-    return _ref
+        _ref[path] = L
+    return _ref[path]
 
 
 class RefSim:
     """One of the reference's own CPU implementations (--im cpu+naive|cpu+optim|cpu+simd|cpu+omp)."""
 
-    def __init__(self, tag, n, scheme="galaxy", soft=SOFT, dt=DT):
-        self.L = ref_lib()
+    def __init__(self, tag, n, scheme="galaxy", soft=SOFT, dt=DT, avx2=False):
+        self.L = ref_lib(avx2)
         self.h = self.L.murbref_create(tag.encode(), n, scheme.encode(), soft, dt)
         if not self.h:
             raise ValueError("unknown reference implementation tag " + tag)
