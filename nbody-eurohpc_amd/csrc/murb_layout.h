@@ -21,7 +21,8 @@
 #define MURB_TILE_BODIES (2 * MURB_TILE_PAIRS)    /* 512 body slots per tile                   */
 #define MURB_TILE_F4 (2 * MURB_TILE_PAIRS)        /* float4 records per tile (A block+B block) */
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+// hipcc sees these helpers from device code too; a plain host compiler (g++) only needs `inline`
+#if defined(__HIPCC__)
 #define MURB_HD __host__ __device__ __forceinline__
 #else
 #define MURB_HD inline

@@ -514,8 +514,8 @@ def test_bench_contract(gpu):
     import subprocess
     import sys
     from conftest import ROOT
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--bodies", "30000", "--steps", "20", "--warmup", "2",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--bodies", "30000", "--steps", "20", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
@@ -532,3 +532,7 @@ def test_bench_contract(gpu):
     assert roof["unit"] == "TFLOP/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert 0.05 < roof["frac"] < 1.0 and d["value"] > 1e12
     assert d["parity"]["max_rel"] <= d["parity"]["tolerance_max_rel"]
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and d["gpu_over_cpu"] > 1
