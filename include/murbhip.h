@@ -64,6 +64,16 @@ unsigned long murbhip_slice_slots(unsigned long n, int world);
 /* Slot of body i in the replicated buffer (rank(i) * slice_slots + offset inside its slice). */
 unsigned long murbhip_slot_of_body(unsigned long n, int world, unsigned long i);
 
+/* The work list of rank `rank` under the multi-GPU pair-symmetric ("half ring") schedule: `*count`
+ * items (i-side sub-block, j-side block), the first `*own_count` of which lie inside the rank's own slice.
+ * A block is 1024 slots, a sub-block 1024/split.  Over all ranks every unordered pair of bodies is
+ * covered exactly once (own-slice items cover both orders inside their diagonal blocks).  `pairs`
+ * (2 ints per item, may be NULL to query the count) must hold `capacity` items.  Replaces the "who
+ * computes what" of the reference's MPI path, which has every rank sweep all j for its i range
+ * (SimulationNBodyMultiNode.cpp:151-170). */
+int murbhip_schedule_items(unsigned long n, int world, int rank, int split, int* pairs, unsigned long capacity,
+                           unsigned long* count, unsigned long* own_count);
+
 /* ------------------------------------------------------------------ life cycle */
 
 /* Number of visible HIP devices. */

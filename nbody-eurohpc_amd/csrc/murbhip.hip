@@ -105,6 +105,36 @@ unsigned long slice_slots(unsigned long n, int world)
     return murb_round_up_tile(std::max(count, 1ul));
 }
 
+// Items (i-side sub-block, j-side block) of rank r under the half-ring pair-symmetric schedule, in launch
+// order; the first `*own` entries are the own-slice triangle.  Host only (no HIP call): the rule that
+// every unordered body pair is evaluated by exactly one rank lives here and is unit-tested on the CPU.
+//   own slice x own slice : sub-block i against block j of the same slice, block(i) <= j
+//   own slice x slice r+d : d = 1 .. floor(W/2), all (sub-block, block) combinations; for even W the slice
+//                           pair half a ring apart is shared and cut at a block boundary of the LOWER
+//                           rank's slice: the lower rank walks its first ceil(tb/2) blocks against all of
+//                           the other slice, the higher rank walks all of its own against the rest
+void sym_schedule_items(int world, int rank, int tb, int split, std::vector<int>& flat, int* own)
+{
+    const int W = world, r = rank, ts = tb * split;
+    flat.clear();
+    for (int j = 0; j < tb; ++j)
+        for (int i = 0; i < (j + 1) * split; ++i) { flat.push_back(r * ts + i); flat.push_back(r * tb + j); }
+    *own = (int)flat.size() / 2;
+    for (int d = 1; d <= W / 2; ++d) {
+        const int s = (r + d) % W;
+        if (s == r) continue;
+        const bool shared = (W % 2 == 0) && d == W / 2;
+        const int lo = std::min(r, s), hb = (tb + 1) / 2;
+        for (int i = 0; i < ts; ++i)
+            for (int j = 0; j < tb; ++j) {
+                // i: OWN sub-blocks (walked, i side); j: the other slice's blocks (LDS resident, j side)
+                if (shared && !((r == lo) ? (i / split < hb) : (j >= hb))) continue;
+                flat.push_back(r * ts + i);
+                flat.push_back(s * tb + j);
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------ context
 struct Shard {
     int device = 0;
@@ -491,11 +521,11 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split)
     const int W = c->world, r = sh.rank;
     const int tb = (int)(c->slice / MURB_SYM_BLOCK);   // blocks per slice
     const int ts = tb * split;                          // i-side sub-blocks per slice
-    std::vector<int2> items;
-    // own slice x own slice: sub-block i against block j of the same slice, block(i) <= j
-    for (int j = 0; j < tb; ++j)
-        for (int i = 0; i < (j + 1) * split; ++i) items.push_back(make_int2(r * ts + i, r * tb + j));
-    const int own = (int)items.size();
+    std::vector<int> flat;
+    int own = 0;
+    sym_schedule_items(W, r, tb, split, flat, &own);
+    std::vector<int2> items(flat.size() / 2);
+    for (size_t k = 0; k < items.size(); ++k) items[k] = make_int2(flat[2 * k], flat[2 * k + 1]);
     MurbSymRowRanges rr{};
     rr.nslices = W;
     rr.blocks_per_slice = tb;
@@ -519,21 +549,6 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split)
     for (int d = 1; d <= W / 2; ++d) {
         const int s = (r + d) % W;
         if (s == r) continue;
-        const bool shared = (W % 2 == 0) && d == W / 2;
-        const int lo = std::min(r, s);
-        for (int i = 0; i < ts; ++i)
-            for (int j = 0; j < tb; ++j) {
-                // i: OWN sub-blocks (walked, i side); j: the other slice's blocks (LDS resident, j side)
-                if (shared) {
-                    // the two ranks half a ring apart share this slice pair; it is cut at a block boundary of
-                    // the LOWER rank's slice: the lower rank walks its first hb blocks against all of the
-                    // other slice, the higher rank walks all of its own against the remaining blocks
-                    const int hb = (tb + 1) / 2;
-                    const bool mine = (r == lo) ? (i / split < hb) : (j >= hb);
-                    if (!mine) continue;
-                }
-                items.push_back(make_int2(r * ts + i, s * tb + j));
-            }
         // bodies of slice s receive j-side sums in the rows of OWN sub-blocks
         rr.first[s][0] = r * ts;
         rr.count[s][0] = ts;
@@ -862,6 +877,23 @@ unsigned long murbhip_slot_of_body(unsigned long n, int world, unsigned long i)
     if (i < rem * (base + 1)) { r = i / (base + 1); first = r * (base + 1); }
     else { r = rem + (base ? (i - rem * (base + 1)) / base : 0); first = rem * (base + 1) + (r - rem) * base; }
     return r * slice_slots(n, world) + (i - first);
+}
+
+int murbhip_schedule_items(unsigned long n, int world, int rank, int split, int* pairs, unsigned long capacity,
+                           unsigned long* count, unsigned long* own_count)
+{
+    if (world < 1 || world > MURB_SYM_MAX_RANKS || rank < 0 || rank >= world || !count || !own_count) return MURBHIP_E_INVALID;
+    if (split != 1 && split != 2 && split != 4 && split != 8 && split != 16) return MURBHIP_E_INVALID;
+    std::vector<int> flat;
+    int own = 0;
+    sym_schedule_items(world, rank, (int)(slice_slots(n, world) / MURB_SYM_BLOCK), split, flat, &own);
+    *count = flat.size() / 2;
+    *own_count = (unsigned long)own;
+    if (pairs) {
+        if (capacity < flat.size() / 2) return MURBHIP_E_INVALID;
+        std::memcpy(pairs, flat.data(), flat.size() * sizeof(int));
+    }
+    return 0;
 }
 
 int murbhip_device_count(int* count)

@@ -43,6 +43,8 @@ def lib():
         L.murbhip_slice_slots.argtypes = [C.c_ulong, C.c_int]
         L.murbhip_slot_of_body.restype = C.c_ulong
         L.murbhip_slot_of_body.argtypes = [C.c_ulong, C.c_int, C.c_ulong]
+        L.murbhip_schedule_items.argtypes = [C.c_ulong, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_ulong,
+                                             C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]
         L.murbhip_device_count.argtypes = [C.POINTER(C.c_int)]
         L.murbhip_create.argtypes = [C.POINTER(C.c_void_p), C.c_ulong, C.c_float, C.c_float, C.c_int]
         L.murbhip_create_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_ulong, C.c_float, C.c_float, C.c_int,
@@ -67,6 +69,7 @@ def lib():
 
 
 EXPORTS = ("murbhip_version murbhip_error_string murbhip_partition murbhip_slice_slots murbhip_slot_of_body "
+           "murbhip_schedule_items "
            "murbhip_device_count murbhip_create murbhip_create_sharded murbhip_unique_id murbhip_create_rank "
            "murbhip_destroy murbhip_upload murbhip_download_state murbhip_download_acc murbhip_compute_acc "
            "murbhip_step murbhip_steps murbhip_integrate_host_acc murbhip_sync murbhip_energy murbhip_set_option "
@@ -103,6 +106,18 @@ def slice_slots(n, world):
 
 def slot_of_body(n, world, i):
     return lib().murbhip_slot_of_body(n, world, i)
+
+
+def schedule_items(n, world, rank, split=1):
+    """(items, own_count): the half-ring work list of `rank`; items is an (count, 2) int array of
+    (i-side sub-block, j-side block)."""
+    count, own = C.c_ulong(), C.c_ulong()
+    _check(lib().murbhip_schedule_items(n, world, rank, split, None, 0, C.byref(count), C.byref(own)),
+           "murbhip_schedule_items")
+    items = np.zeros((count.value, 2), np.int32)
+    _check(lib().murbhip_schedule_items(n, world, rank, split, items.ctypes.data_as(C.POINTER(C.c_int)), count.value,
+                                        C.byref(count), C.byref(own)), "murbhip_schedule_items")
+    return items, own.value
 
 
 def device_count():

@@ -128,3 +128,44 @@ def test_driver_cli_contract():
     assert r.returncode == 255 and "Implementation 'cpu+nope' does not exist... Exiting." in r.stdout
     r = subprocess.run([exe, "-n", "100", "-i", "1", "--soft", "0"], capture_output=True, text=True)
     assert r.returncode == 255 and "Softening factor can't be equal to 0" in r.stdout
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 5, 6, 8])
+@pytest.mark.parametrize("n,split", [(9000, 1), (9000, 4), (30000, 2), (200000, 1)])
+def test_half_ring_schedule_covers_every_pair_once(mh, n, world, split):
+    """Multi-GPU pair-symmetric schedule (murbhip_schedule_items, host only): over all ranks every
+    unordered pair of (sub-block, block) cells is listed exactly once, each rank's share is balanced,
+    and a rank only ever walks sub-blocks of its own slice on the i side."""
+    if n // world < 1024 and world > 4:
+        pytest.skip("slices of one block: nothing to balance")
+    tb = mh.slice_slots(n, world) // 1024
+    ts = tb * split
+    seen = {}
+    counts = []
+    for r in range(world):
+        items, own = mh.schedule_items(n, world, r, split)
+        counts.append(len(items))
+        assert own == split * tb * (tb + 1) // 2
+        for k, (i, j) in enumerate(items.tolist()):
+            assert r * ts <= i < (r + 1) * ts, "i side must be an own sub-block"
+            if k < own:
+                assert r * tb <= j < (r + 1) * tb and i // split <= j
+            else:
+                assert not (r * tb <= j < (r + 1) * tb)
+            # canonical key of the unordered cell {sub-block i, block j}: own-slice items are ordered
+            # (block(i) <= j) and unique by construction; a rectangle cell {i, j} could also be listed by
+            # the rank owning j as (some sub-block of j, block(i)): express both in sub-block pairs
+            for jj in range(j * split, (j + 1) * split):
+                if i // split == j:            # diagonal block: both orders evaluated inside the item
+                    key = ("diag", i, jj)
+                else:
+                    key = ("off", min(i, jj), max(i, jj))
+                seen[key] = seen.get(key, 0) + 1
+    assert all(v == 1 for v in seen.values()), "a cell is evaluated twice"
+    total_sub = world * ts
+    off = sum(1 for k in seen if k[0] == "off")
+    diag = sum(1 for k in seen if k[0] == "diag")
+    assert diag == world * tb * split * split                      # every (sub-block, sub-block) cell of a diagonal block
+    assert off == (total_sub * total_sub - world * tb * split * split) // 2   # every other unordered pair exactly once
+    if world > 1 and tb >= 2:
+        assert max(counts) - min(counts) <= split * tb, counts     # balanced up to one block row
