@@ -7,8 +7,9 @@
 // in fp32, full N^2 form (the j == i term is exactly 0 because q_j - q_i = 0 and soft > 0).
 //
 // How it is mapped to the machine (this is NOT the reference's one-thread-per-body tiling):
-//   * the i bodies of a wavefront are wave-uniform: R of them live in SGPRs, so every VALU
-//     instruction reads its i operand from the scalar file for free;
+//   * the i bodies of a wavefront are wave-uniform: R of them live in SGPRs (loaded once per sweep,
+//     moved with v_readfirstlane), so every VALU instruction reads its i operand from the scalar
+//     file for free;
 //   * the j bodies are spread over the 64 lanes, two per lane, in the pair layout of murb_layout.h,
 //     so the twelve arithmetic instructions of an interaction issue as packed fp32
 //     (v_pk_add/v_pk_mul/v_pk_fma_f32) on two interactions at once; only v_rsq_f32 is per element;
