@@ -159,6 +159,8 @@ int murbhip_energy(murbhip_ctx* ctx, double* kinetic, double* potential);
  *                    variant: scheduling rounds (workgroups per resident slot).  0 = auto
  *   "profile"        1: bracket every force kernel with HIP events (read with murbhip_get_info)
  *   "overlap"        sharded/rank mode: 1 (default) own-slice tiles first, exchange on the 2nd stream
+ *   "solo_shard"     r >= 0: in a sharded context only shard r launches force work (timing aid: the
+ *                    isolated per-step timeline of one rank of W; results are meaningless).  -1 = off
  *   "force_exchange" 1: run the position exchange even with a single rank/shard (self-test of the
  *                    RCCL binding on a one-GPU machine; rank mode needs a unique id at creation)
  */

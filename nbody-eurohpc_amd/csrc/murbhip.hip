@@ -186,6 +186,8 @@ struct murbhip_ctx {
     // options
     int variant = 0, jsplit = 0, profile = 0, overlap = 1;
     int force_exchange = 0;   // run the exchange even with one rank (self-test of the RCCL binding)
+    int solo_shard = -1;      // >= 0: only this shard computes (timing aid: one rank's isolated timeline
+                              // when W shards share one GPU; results are then meaningless)
     // facts
     int cu_count = 0, clock_mhz = 0;
     size_t device_mem = 0;     // bytes of HBM on the first device
@@ -319,9 +321,11 @@ Plan make_plan(const murbhip_ctx* c)
     else p.variant = (sym_items_per_rank(c) >= 400 && planes_fit) ? kSymmetricVariant : kOneSidedVariant;
     p.symmetric = p.variant == kSymmetricVariant;
     if (p.symmetric) {
-        // finer items (i side cut in 2 or 4) until a rank has ~8 scheduling rounds of them
+        // finer items (i side cut in 2 or 4) until a GPU has ~8 scheduling rounds of them; ~16 in the
+        // multi-rank pipeline, whose three force launches per step each end in a tail (measured with
+        // tools/solo_profile.py: N=200k, W=2/4/8 -> split 2/4/4 is best)
         const long items = sym_items_per_rank(c);
-        const long want = 8L * 4 * std::max(c->cu_count, 1);
+        const long want = (c->world > 1 ? 16L : 8L) * 4 * std::max(c->cu_count, 1);
         p.split = (c->jsplit == 1 || c->jsplit == 2 || c->jsplit == 4 || c->jsplit == 8 || c->jsplit == 16)
                       ? c->jsplit
                       : (items >= want ? 1 : (2 * items >= want ? 2 : 4));
@@ -483,6 +487,7 @@ int enqueue_exchange(murbhip_ctx* c, int buf)
                 HIP_TRY(hipStreamWaitEvent(sh.comm, peer.ev_integrated, 0));
             }
             HIP_TRY(hipStreamWaitEvent(sh.comm, sh.ev_integrated, 0));
+            if (c->solo_shard >= 0 && sh.rank != c->solo_shard) continue;   // timing aid
             for (Shard& peer : c->shards) {
                 if (&peer == &sh) continue;
                 const size_t off = (size_t)peer.rank * slice_f4;
@@ -632,16 +637,19 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
         RC_TRY(build_sym_schedule(c, sh, p.split));
+        const bool idle = c->solo_shard >= 0 && sh.rank != c->solo_shard;
         const int own = sh.sym_items_own, t1 = c->overlap ? own / 2 : 0;
-        RC_TRY(enqueue_sym_launch(c, sh, 0, t1, true));
+        if (!idle) RC_TRY(enqueue_sym_launch(c, sh, 0, t1, true));
         if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
-        RC_TRY(enqueue_sym_launch(c, sh, own, sh.sym_items_total - own, false));
+        if (!idle) RC_TRY(enqueue_sym_launch(c, sh, own, sh.sym_items_total - own, false));
         if (c->exchange == 0 && c->reduce_pending)   // peer-read reduce: nobody may still be reading our send buffer
             for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.compute, peer.ev_reduced, 0));
-        hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slots / 64)), dim3(256), 0, sh.compute,
-                           sh.sym_part, sh.sym_split * rows_all, (unsigned int)c->slots, sh.sym_ranges, sh.sym_split,
-                           sh.sym_send);
-        RC_TRY(hip_rc(hipGetLastError()));
+        if (!idle) {
+            hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slots / 64)), dim3(256), 0, sh.compute,
+                               sh.sym_part, sh.sym_split * rows_all, (unsigned int)c->slots, sh.sym_ranges, sh.sym_split,
+                               sh.sym_send);
+            RC_TRY(hip_rc(hipGetLastError()));
+        }
         HIP_TRY(hipEventRecord(sh.ev_rowsum, sh.compute));
         c->interactions_per_launch = (double)sh.count * (double)c->n;
     }
@@ -667,6 +675,7 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
         for (Shard& sh : c->shards) {
             HIP_TRY(hipSetDevice(sh.device));
             for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.comm, peer.ev_rowsum, 0));
+            if (c->solo_shard >= 0 && sh.rank != c->solo_shard) continue;
             hipLaunchKernelGGL(murb_sym_peer_sum_kernel, dim3((chunk_floats + 255) / 256), dim3(256), 0, sh.comm, peers,
                                (unsigned long)sh.rank * chunk_floats, chunk_floats, sh.sym_recv);
             RC_TRY(hip_rc(hipGetLastError()));
@@ -677,6 +686,8 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
         HIP_TRY(hipEventRecord(sh.ev_reduced, sh.comm));
         // meanwhile: the rest of the own-slice triangle and its row sum
         const int own = sh.sym_items_own, t1 = c->overlap ? own / 2 : 0;
+        const bool idle = c->solo_shard >= 0 && sh.rank != c->solo_shard;
+        if (idle) continue;   // timing aid: this shard only takes part in the event/exchange skeleton
         RC_TRY(enqueue_sym_launch(c, sh, t1, own - t1, true));
         hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slice / 64)), dim3(256), 0, sh.compute,
                            sh.sym_tri, sh.sym_split * rows_own, (unsigned int)c->slice,
@@ -714,6 +725,7 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
     if (p.symmetric && (c->world > 1 || c->force_exchange)) return enqueue_iteration_sym_multi(c, p, dt, update_state);
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
+        if (c->solo_shard >= 0 && sh.rank != c->solo_shard) continue;   // timing aid: see "solo_shard"
         if (c->world == 1) {
             if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
             RC_TRY(enqueue_force(c, sh, p, 0));
@@ -1169,6 +1181,7 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     if (k == "variant") { if (value < 0 || value > kNumVariants) return MURBHIP_E_INVALID; c->variant = (int)value; }
     else if (k == "jsplit") { if (value < 0 || value > kMaxParts / 2) return MURBHIP_E_INVALID; c->jsplit = (int)value; }
     else if (k == "overlap") c->overlap = value ? 1 : 0;
+    else if (k == "solo_shard") c->solo_shard = (int)value;
     else if (k == "force_exchange") {
         if (value && c->exchange == 1 && !c->shards[0].comm_rccl) return MURBHIP_E_STATE;
         c->force_exchange = value ? 1 : 0;
