@@ -153,10 +153,11 @@ int murbhip_energy(murbhip_ctx* ctx, double* kinetic, double* potential);
 /* ------------------------------------------------------------------ tuning and measurement */
 
 /* Integer options.  Keys:
- *   "variant"        force kernel variant (0 = auto: pair-symmetric kernel (8) on one GPU
- *                    from 18 432 bodies up, one-sided kernel (1) otherwise)
- *   "jsplit"         2-D grid variants: number of j-chunks a body's sum is split into; persistent
- *                    variant: scheduling rounds (workgroups per resident slot).  0 = auto
+ *   "variant"        force kernel variant.  0 = auto: the pair-symmetric kernel (8) on one
+ *                    GPU from 18 432 bodies up and in multi-GPU runs when a rank gets >= 400 block pairs,
+ *                    the one-sided kernel (1) otherwise.  1-6: one-sided variants, 7: persistent schedule
+ *   "jsplit"         one-sided variants: number of j-chunks a body's sum is split into; variant 7:
+ *                    scheduling rounds; variant 8: i-side sub-blocks per item (1, 2, 4, 8, 16).  0 = auto
  *   "profile"        1: bracket every force kernel with HIP events (read with murbhip_get_info)
  *   "overlap"        sharded/rank mode: 1 (default) own-slice tiles first, exchange on the 2nd stream
  *   "solo_shard"     r >= 0: in a sharded context only shard r launches force work (timing aid: the
