@@ -7,10 +7,15 @@
 //     enqueueing 2-3 kernels;
 //   * positions are double-buffered: a step reads rec[cur] and the integrate kernel writes
 //     rec[cur^1], so no kernel ever reads a buffer another kernel (or a peer GPU) is writing;
-//   * multi-GPU: bodies are block-partitioned (murbhip_partition) into equal tile-aligned slot
-//     ranges of one replicated record buffer; after its integrate a shard publishes its slice with
-//     ONE in-place all-gather (RCCL, loaded lazily with dlopen) or with peer copies, on a second
-//     stream, while the compute stream already sweeps the j tiles of its own slice.
+//   * force kernels: the pair-symmetric kernel (murb_kernels_sym.h; every body pair once, both
+//     directions) wherever a GPU gets enough block pairs, the one-sided kernel (murb_kernels.h)
+//     otherwise; make_plan() decides, "variant"/"jsplit" override;
+//   * multi-GPU: bodies are block-partitioned (murbhip_partition) into equal block-aligned slot
+//     ranges of one replicated record buffer.  Half-ring schedule (sym_schedule_items): every pair is
+//     evaluated by exactly one rank, ONE reduce-scatter returns each rank the accelerations of its own
+//     bodies, ONE in-place all-gather publishes the integrated slice; both run on a second,
+//     high-priority stream (RCCL, bound lazily with dlopen, or peer copies/peer reads inside one
+//     process) under the two halves of the own-slice triangle (enqueue_iteration_sym_multi).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
