@@ -159,7 +159,9 @@ int murbhip_energy(murbhip_ctx* ctx, double* kinetic, double* potential);
  *   "jsplit"         one-sided variants: number of j-chunks a body's sum is split into; variant 7:
  *                    scheduling rounds; variant 8: i-side sub-blocks per item (1, 2, 4, 8, 16).  0 = auto
  *   "profile"        1: bracket every force kernel with HIP events (read with murbhip_get_info)
- *   "overlap"        sharded/rank mode: 1 (default) own-slice tiles first, exchange on the 2nd stream
+ *   "overlap"        sharded/rank mode: 0 = no overlap; 1 (default) = the own-slice work brackets the
+ *                    exchanges on the compute stream; 2 = the own-slice triangle runs on a second,
+ *                    lowest-priority compute stream next to the rectangle launch (pair-symmetric only)
  *   "solo_shard"     r >= 0: in a sharded context only shard r launches force work (timing aid: the
  *                    isolated per-step timeline of one rank of W; results are meaningless).  -1 = off
  *   "force_exchange" 1: run the position exchange even with a single rank/shard (self-test of the

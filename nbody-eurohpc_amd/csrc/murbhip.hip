@@ -146,7 +146,8 @@ struct Shard {
     int rank = 0;
     unsigned long first = 0, count = 0;   // global body range owned
     hipStream_t compute = nullptr, comm = nullptr;
-    hipEvent_t ev_integrated = nullptr, ev_gathered = nullptr;
+    hipStream_t compute_low = nullptr;   // lowest priority: the own-slice triangle in "overlap" mode 2
+    hipEvent_t ev_integrated = nullptr, ev_gathered = nullptr, ev_tri = nullptr;
     float4* rec[2] = {nullptr, nullptr};
     float4* vel = nullptr;
     float4* accp = nullptr;
@@ -213,6 +214,9 @@ struct Plan {
 };
 
 constexpr int kPotentialKernel = 100;   // not a selectable variant: murbhip_energy's potential sweep
+
+// "solo_shard" timing aid: every shard but one stays completely idle
+inline bool is_idle(const murbhip_ctx* c, const Shard& sh) { return c->solo_shard >= 0 && sh.rank != c->solo_shard; }
 
 template <int MODE, int R, int WAVES, int STAGE>
 int launch_force_t(const MurbForceArgs& a, int i_slots, hipStream_t s)
@@ -384,7 +388,8 @@ int prof_end(murbhip_ctx* c, Shard& sh)
 }
 
 int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split);
-int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_planes = false);
+int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_planes = false,
+                       hipStream_t stream = nullptr);
 
 // Force over the tiles of `which` (0 = own slice / everything when world == 1, 1 = all but own slice).
 int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
@@ -466,6 +471,7 @@ int enqueue_exchange(murbhip_ctx* c, int buf)
     const size_t slice_f4 = c->slice;                  // float4 records per slice (1 per body slot)
     const size_t slice_bytes = slice_f4 * sizeof(float4);
     for (Shard& sh : c->shards) {
+        if (is_idle(c, sh)) continue;
         HIP_TRY(hipSetDevice(sh.device));
         HIP_TRY(hipEventRecord(sh.ev_integrated, sh.compute));
     }
@@ -486,13 +492,13 @@ int enqueue_exchange(murbhip_ctx* c, int buf)
     } else {
         // pull model: each shard copies every peer's slice out of the peer's buffer
         for (Shard& sh : c->shards) {
+            if (is_idle(c, sh)) continue;
             HIP_TRY(hipSetDevice(sh.device));
             for (Shard& peer : c->shards) {
                 if (&peer == &sh) continue;
                 HIP_TRY(hipStreamWaitEvent(sh.comm, peer.ev_integrated, 0));
             }
             HIP_TRY(hipStreamWaitEvent(sh.comm, sh.ev_integrated, 0));
-            if (c->solo_shard >= 0 && sh.rank != c->solo_shard) continue;   // timing aid
             for (Shard& peer : c->shards) {
                 if (&peer == &sh) continue;
                 const size_t off = (size_t)peer.rank * slice_f4;
@@ -506,6 +512,7 @@ int enqueue_exchange(murbhip_ctx* c, int buf)
         }
     }
     for (Shard& sh : c->shards) {
+        if (is_idle(c, sh)) continue;
         HIP_TRY(hipSetDevice(sh.device));
         HIP_TRY(hipEventRecord(sh.ev_gathered, sh.comm));
     }
@@ -596,9 +603,10 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split)
     return 0;
 }
 
-int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_planes)
+int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_planes, hipStream_t stream)
 {
     if (count <= 0) return 0;
+    if (!stream) stream = sh.compute;
     MurbSymArgs sa{};
     sa.rec = sh.rec[c->cur];
     sa.items = sh.sym_items;
@@ -616,10 +624,11 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
         sa.row_stride = (unsigned int)c->slots;
     }
     sa.soft2 = c->soft2;
-    RC_TRY(prof_begin(c, sh));
-    hipLaunchKernelGGL(murb_force_sym_kernel<4>, dim3((unsigned)count), dim3(256), 0, sh.compute, sa);
+    const bool timed = stream == sh.compute;   // the profiling events live on the main compute stream
+    if (timed) RC_TRY(prof_begin(c, sh));
+    hipLaunchKernelGGL(murb_force_sym_kernel<4>, dim3((unsigned)count), dim3(256), 0, stream, sa);
     RC_TRY(hip_rc(hipGetLastError()));
-    RC_TRY(prof_end(c, sh));
+    if (timed) RC_TRY(prof_end(c, sh));
     return 0;
 }
 
@@ -642,19 +651,28 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
         RC_TRY(build_sym_schedule(c, sh, p.split));
-        const bool idle = c->solo_shard >= 0 && sh.rank != c->solo_shard;
-        const int own = sh.sym_items_own, t1 = c->overlap ? own / 2 : 0;
-        if (!idle) RC_TRY(enqueue_sym_launch(c, sh, 0, t1, true));
+        if (is_idle(c, sh)) continue;   // "solo_shard" timing aid: idle shards enqueue nothing at all
+        const int own = sh.sym_items_own, t1 = c->overlap == 1 ? own / 2 : 0;
+        if (c->overlap == 2) {
+            // the whole own-slice triangle on a second, lowest-priority compute stream: it runs alone while
+            // the positions are still being gathered, then fills the gaps and the tail of the rectangles
+            if (c->gather_pending || c->reduce_pending) HIP_TRY(hipStreamWaitEvent(sh.compute_low, sh.ev_integrated, 0));
+            RC_TRY(enqueue_sym_launch(c, sh, 0, own, true, sh.compute_low));
+            hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slice / 64)), dim3(256), 0, sh.compute_low,
+                               sh.sym_tri, sh.sym_split * rows_own, (unsigned int)c->slice,
+                               (const MurbSymRowRanges*)nullptr, sh.sym_split, sh.sym_tri_acc);
+            RC_TRY(hip_rc(hipGetLastError()));
+            HIP_TRY(hipEventRecord(sh.ev_tri, sh.compute_low));
+        }
+        RC_TRY(enqueue_sym_launch(c, sh, 0, t1, true));
         if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
-        if (!idle) RC_TRY(enqueue_sym_launch(c, sh, own, sh.sym_items_total - own, false));
+        RC_TRY(enqueue_sym_launch(c, sh, own, sh.sym_items_total - own, false));
         if (c->exchange == 0 && c->reduce_pending)   // peer-read reduce: nobody may still be reading our send buffer
             for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.compute, peer.ev_reduced, 0));
-        if (!idle) {
-            hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slots / 64)), dim3(256), 0, sh.compute,
-                               sh.sym_part, sh.sym_split * rows_all, (unsigned int)c->slots, sh.sym_ranges, sh.sym_split,
-                               sh.sym_send);
-            RC_TRY(hip_rc(hipGetLastError()));
-        }
+        hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slots / 64)), dim3(256), 0, sh.compute,
+                           sh.sym_part, sh.sym_split * rows_all, (unsigned int)c->slots, sh.sym_ranges, sh.sym_split,
+                           sh.sym_send);
+        RC_TRY(hip_rc(hipGetLastError()));
         HIP_TRY(hipEventRecord(sh.ev_rowsum, sh.compute));
         c->interactions_per_launch = (double)sh.count * (double)c->n;
     }
@@ -678,26 +696,29 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
         peers.n = (int)c->shards.size();
         for (size_t k = 0; k < c->shards.size(); ++k) peers.p[c->shards[k].rank] = c->shards[k].sym_send;
         for (Shard& sh : c->shards) {
+            if (is_idle(c, sh)) continue;
             HIP_TRY(hipSetDevice(sh.device));
             for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.comm, peer.ev_rowsum, 0));
-            if (c->solo_shard >= 0 && sh.rank != c->solo_shard) continue;
             hipLaunchKernelGGL(murb_sym_peer_sum_kernel, dim3((chunk_floats + 255) / 256), dim3(256), 0, sh.comm, peers,
                                (unsigned long)sh.rank * chunk_floats, chunk_floats, sh.sym_recv);
             RC_TRY(hip_rc(hipGetLastError()));
         }
     }
     for (Shard& sh : c->shards) {
+        if (is_idle(c, sh)) continue;
         HIP_TRY(hipSetDevice(sh.device));
         HIP_TRY(hipEventRecord(sh.ev_reduced, sh.comm));
         // meanwhile: the rest of the own-slice triangle and its row sum
-        const int own = sh.sym_items_own, t1 = c->overlap ? own / 2 : 0;
-        const bool idle = c->solo_shard >= 0 && sh.rank != c->solo_shard;
-        if (idle) continue;   // timing aid: this shard only takes part in the event/exchange skeleton
-        RC_TRY(enqueue_sym_launch(c, sh, t1, own - t1, true));
-        hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slice / 64)), dim3(256), 0, sh.compute,
-                           sh.sym_tri, sh.sym_split * rows_own, (unsigned int)c->slice,
-                           (const MurbSymRowRanges*)nullptr, sh.sym_split, sh.sym_tri_acc);
-        RC_TRY(hip_rc(hipGetLastError()));
+        const int own = sh.sym_items_own, t1 = c->overlap == 1 ? own / 2 : 0;
+        if (c->overlap == 2) {
+            HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_tri, 0));
+        } else {
+            RC_TRY(enqueue_sym_launch(c, sh, t1, own - t1, true));
+            hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slice / 64)), dim3(256), 0, sh.compute,
+                               sh.sym_tri, sh.sym_split * rows_own, (unsigned int)c->slice,
+                               (const MurbSymRowRanges*)nullptr, sh.sym_split, sh.sym_tri_acc);
+            RC_TRY(hip_rc(hipGetLastError()));
+        }
         HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
         MurbIntegrateArgs a{};
         a.rec_in = sh.rec[c->cur];
@@ -714,6 +735,7 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
         a.update_state = update_state;
         hipLaunchKernelGGL(murb_integrate_kernel, dim3((unsigned)((c->slice / 2 + 255) / 256)), dim3(256), 0, sh.compute, a);
         RC_TRY(hip_rc(hipGetLastError()));
+        if (!update_state) HIP_TRY(hipEventRecord(sh.ev_integrated, sh.compute));   // else enqueue_exchange records it
     }
     c->reduce_pending = true;
     if (update_state) {
@@ -730,7 +752,7 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
     if (p.symmetric && (c->world > 1 || c->force_exchange)) return enqueue_iteration_sym_multi(c, p, dt, update_state);
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
-        if (c->solo_shard >= 0 && sh.rank != c->solo_shard) continue;   // timing aid: see "solo_shard"
+        if (is_idle(c, sh)) continue;   // timing aid: see "solo_shard"
         if (c->world == 1) {
             if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
             RC_TRY(enqueue_force(c, sh, p, 0));
@@ -792,6 +814,12 @@ int create_common(murbhip_ctx** out, unsigned long n, float soft, float g, int w
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
             if ((rc = hip_rc(hipStreamCreateWithPriority(&sh.comm, hipStreamNonBlocking, greatest)))) break;
         }
+        {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if ((rc = hip_rc(hipStreamCreateWithPriority(&sh.compute_low, hipStreamNonBlocking, least)))) break;
+        }
+        if ((rc = hip_rc(hipEventCreateWithFlags(&sh.ev_tri, hipEventDisableTiming)))) break;
         if ((rc = hip_rc(hipEventCreateWithFlags(&sh.ev_integrated, hipEventDisableTiming)))) break;
         if ((rc = hip_rc(hipEventCreateWithFlags(&sh.ev_gathered, hipEventDisableTiming)))) break;
         const size_t rec_bytes = c->slots * sizeof(float4);
@@ -981,6 +1009,8 @@ int murbhip_destroy(murbhip_ctx* c)
         hipSetDevice(sh.device);
         if (sh.compute) hipStreamSynchronize(sh.compute);
         if (sh.comm) hipStreamSynchronize(sh.comm);
+        if (sh.compute_low) { hipStreamSynchronize(sh.compute_low); hipStreamDestroy(sh.compute_low); }
+        if (sh.ev_tri) hipEventDestroy(sh.ev_tri);
         if (sh.comm_rccl && rccl().ok) rccl().CommDestroy(sh.comm_rccl);
         for (hipEvent_t e : sh.prof) hipEventDestroy(e);
         if (sh.ev_integrated) hipEventDestroy(sh.ev_integrated);
@@ -1032,6 +1062,7 @@ int murbhip_sync(murbhip_ctx* c)
     for (Shard& sh : c->shards) {
         int r1 = hip_rc(hipSetDevice(sh.device));
         if (!r1) r1 = hip_rc(hipStreamSynchronize(sh.compute));
+        if (!r1) r1 = hip_rc(hipStreamSynchronize(sh.compute_low));
         if (!r1) r1 = hip_rc(hipStreamSynchronize(sh.comm));
         if (r1 && !rc) rc = r1;
     }
@@ -1185,7 +1216,7 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     const std::string k(key);
     if (k == "variant") { if (value < 0 || value > kNumVariants) return MURBHIP_E_INVALID; c->variant = (int)value; }
     else if (k == "jsplit") { if (value < 0 || value > kMaxParts / 2) return MURBHIP_E_INVALID; c->jsplit = (int)value; }
-    else if (k == "overlap") c->overlap = value ? 1 : 0;
+    else if (k == "overlap") { if (value < 0 || value > 2) return MURBHIP_E_INVALID; c->overlap = (int)value; }
     else if (k == "solo_shard") c->solo_shard = (int)value;
     else if (k == "force_exchange") {
         if (value && c->exchange == 1 && !c->shards[0].comm_rccl) return MURBHIP_E_STATE;

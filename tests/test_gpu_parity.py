@@ -215,7 +215,7 @@ def test_massless_bodies_do_not_pull(gpu, O):
 
 
 @pytest.mark.parametrize("shards", [2, 3, 4, 8])
-@pytest.mark.parametrize("variant,overlap,jsplit", [(1, 1, 0), (1, 0, 0), (8, 1, 0), (8, 0, 1), (8, 1, 2)])
+@pytest.mark.parametrize("variant,overlap,jsplit", [(1, 1, 0), (1, 0, 0), (8, 1, 0), (8, 0, 1), (8, 1, 2), (8, 2, 0), (8, 2, 4)])
 def test_sharded_matches_single(gpu, O, shards, variant, overlap, jsplit):
     """Body-range partition + per-step position exchange, several shards time-sharing one GPU.
     variant 1: every rank sweeps all j for its own i slice (one-sided).  variant 8: half-ring
