@@ -150,6 +150,15 @@ int murbhip_sync(murbhip_ctx* ctx);
  * the acceleration output: murbhip_download_acc() returns it (x plane) until the next step. */
 int murbhip_energy(murbhip_ctx* ctx, double* kinetic, double* potential);
 
+/* First moments of the current state, fp64 sums on the host over the caller's own bodies:
+ *   out10 = { Px, Py, Pz,  Lx, Ly, Lz,  Mx, My, Mz,  M }
+ * linear momentum sum m v, angular momentum sum m (q x v), mass-weighted position sum m q and total
+ * mass (centre of mass = M{x,y,z} / M).  These fill the ang_momentum / density_center columns the
+ * reference's SimulationHistory reserves but never computes (SimulationHistory.hpp:13-15,
+ * SimulationNBodyCUDAPropertyTracking.cu:5-8: only COMPUTE_ENERGY_METRIC is enabled).  In rank mode
+ * sum the ten values over ranks. */
+int murbhip_moments(murbhip_ctx* ctx, double* out10);
+
 /* ------------------------------------------------------------------ tuning and measurement */
 
 /* Integer options.  Keys:
@@ -162,6 +171,12 @@ int murbhip_energy(murbhip_ctx* ctx, double* kinetic, double* potential);
  *   "overlap"        sharded/rank mode: 0 = no overlap; 1 (default) = the own-slice work brackets the
  *                    exchanges on the compute stream; 2 = the own-slice triangle runs on a second,
  *                    lowest-priority compute stream next to the rectangle launch (pair-symmetric only)
+ *   "integrator"     0 (default) = the reference's update, Bodies.cpp:260-278; 1 = kick-drift-kick
+ *                    leapfrog, the scheme the reference's gpu+leapfrog states (CUDABodies.cu:172-178) with
+ *                    the force taken at the positions it belongs to: one force evaluation per step, the
+ *                    device keeps v_{n-1/2}, murbhip_download_state applies the closing half kick (one
+ *                    extra force evaluation; a collective in rank mode).  Cannot be changed between a
+ *                    leapfrog step and the next murbhip_upload (MURBHIP_E_STATE)
  *   "solo_shard"     r >= 0: in a sharded context only shard r launches force work (timing aid: the
  *                    isolated per-step timeline of one rank of W; results are meaningless).  -1 = off
  *   "force_exchange" 1: run the position exchange even with a single rank/shard (self-test of the

@@ -366,6 +366,8 @@ struct MurbIntegrateArgs {
     unsigned int acc_stride;
     float dt;
     int update_state;        // 0: only reduce partial sums into acc_out
+    int scheme;              // 0: the reference's update ; 1: leapfrog kick-drift (see murb_integrate_kernel)
+    float kick_dt;           // scheme 1: length of the velocity kick ending at this step's mid point
     const float* acc_planes; // accelerations ax | ay | az (acc_stride each): row sums, or a reduce-scatter's output
     const float* acc_planes2;// optional second addend of the same shape (own-slice part that skipped the reduce-scatter)
     int nsched;              // persistent launches that produced accp (0, 1 or 2)
@@ -445,6 +447,27 @@ __global__ __launch_bounds__(256) void murb_integrate_kernel(const MurbIntegrate
     float4 A = a.rec_in[ra], B = a.rec_in[ra + MURB_TILE_PAIRS];
     float4 VA = a.vel[va], VB = a.vel[va + MURB_TILE_PAIRS];
     const float dt = a.dt;
+    if (a.scheme == 1) {
+        // Kick-drift-kick leapfrog in its one-force-per-step form: the stored velocity lags the positions
+        // by half a step, v_{n+1/2} = v_{n-1/2} + a_n*kick_dt, q_{n+1} = q_n + v_{n+1/2}*dt (the drift keeps
+        // the reference integrator's fp64 intermediate).  The closing half kick is applied on read-out
+        // (murbhip_download_state).  The formulation is the one the reference states but does not
+        // implement (CUDABodies.cu:172-178: its kernels take a_n at the positions of step n-1).
+        const float h = a.kick_dt;
+        if (s0 < a.count) {
+            VA.x = murb_add_rounded(VA.x, murb_kick(acc0.x, h)); VA.z = murb_add_rounded(VA.z, murb_kick(acc0.y, h));
+            VB.x = murb_add_rounded(VB.x, murb_kick(acc0.z, h));
+            A.x = murb_drift(A.x, VA.x, 0.f, dt); A.z = murb_drift(A.z, VA.z, 0.f, dt); B.x = murb_drift(B.x, VB.x, 0.f, dt);
+        }
+        if (s0 + 1 < a.count) {
+            VA.y = murb_add_rounded(VA.y, murb_kick(acc1.x, h)); VA.w = murb_add_rounded(VA.w, murb_kick(acc1.y, h));
+            VB.y = murb_add_rounded(VB.y, murb_kick(acc1.z, h));
+            A.y = murb_drift(A.y, VA.y, 0.f, dt); A.w = murb_drift(A.w, VA.w, 0.f, dt); B.y = murb_drift(B.y, VB.y, 0.f, dt);
+        }
+        a.rec_out[ra] = A; a.rec_out[ra + MURB_TILE_PAIRS] = B;
+        a.vel[va] = VA; a.vel[va + MURB_TILE_PAIRS] = VB;
+        return;
+    }
     if (s0 < a.count) {
         const float kx = murb_kick(acc0.x, dt), ky = murb_kick(acc0.y, dt), kz = murb_kick(acc0.z, dt);
         A.x = murb_drift(A.x, VA.x, kx, dt); A.z = murb_drift(A.z, VA.z, ky, dt); B.x = murb_drift(B.x, VB.x, kz, dt);

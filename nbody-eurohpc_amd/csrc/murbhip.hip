@@ -191,6 +191,9 @@ struct murbhip_ctx {
     bool reduce_pending = false;   // peers may still be reading this context's reduce-scatter send buffers
     // options
     int variant = 0, jsplit = 0, profile = 0, overlap = 1;
+    int integrator = 0;       // 0 the reference's update (Bodies.cpp:260-278), 1 kick-drift-kick leapfrog
+    bool lf_half = false;     // leapfrog: device velocities lag the positions by half a step of lf_last_dt
+    float lf_last_dt = 0.f;
     int force_exchange = 0;   // run the exchange even with one rank (self-test of the RCCL binding)
     int solo_shard = -1;      // >= 0: only this shard computes (timing aid: one rank's isolated timeline
                               // when W shards share one GPU; results are then meaningless)
@@ -439,9 +442,16 @@ int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
     return 0;
 }
 
-int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int update_state, const Plan* plan = nullptr)
+// Leapfrog kick length for a step of `dt`: half of it on the first step after an upload, otherwise
+// the second half of the previous step's kick plus the first half of this one's.
+inline float leapfrog_kick(const murbhip_ctx* c, float dt) { return c->lf_half ? 0.5f * (c->lf_last_dt + dt) : 0.5f * dt; }
+
+int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int update_state, const Plan* plan = nullptr,
+                      int scheme = -1)
 {
     MurbIntegrateArgs a{};
+    a.scheme = scheme >= 0 ? scheme : c->integrator;
+    a.kick_dt = leapfrog_kick(c, dt);
     if (plan && plan->symmetric) a.acc_planes = sh.sym_recv;   // written by murb_sym_rowsum_kernel
     if (plan && plan->persistent) {
         a.group_bodies = 32;
@@ -728,6 +738,8 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
         a.acc_out = sh.acc_out;
         a.acc_planes = sh.sym_recv;
         a.acc_planes2 = sh.sym_tri_acc;
+        a.scheme = c->integrator;
+        a.kick_dt = leapfrog_kick(c, dt);
         a.i_first_slot = (int)((unsigned long)sh.rank * c->slice);
         a.count = (int)sh.count;
         a.acc_stride = (unsigned int)c->slice;
@@ -1052,8 +1064,19 @@ int murbhip_upload(murbhip_ctx* c, const float* qx, const float* qy, const float
     c->cur = 0;
     c->gather_pending = false;
     c->uploaded = true;
+    c->lf_half = false;
     return 0;
 }
+
+namespace {
+// v + a*h with the product rounded on its own, like the device kicks (murb_kernels.h)
+float half_kick(float v, float a, float h)
+{
+#pragma clang fp contract(off)
+    const float k = a * h;
+    return v + k;
+}
+}  // namespace
 
 int murbhip_sync(murbhip_ctx* c)
 {
@@ -1074,8 +1097,13 @@ int murbhip_download_state(murbhip_ctx* c, float* qx, float* qy, float* qz, floa
 {
     if (!c) return MURBHIP_E_INVALID;
     if (!c->uploaded) return MURBHIP_E_STATE;
+    // leapfrog: the device holds v_{n-1/2}; what the caller gets is v_n = v_{n-1/2} + a(q_n)*dt/2, which
+    // costs one force evaluation (in one-process-per-GPU mode that makes this call a collective)
+    const bool closing_kick = c->lf_half && (vx || vy || vz);
+    if (closing_kick) RC_TRY(enqueue_iteration(c, 0.f, 0));
     RC_TRY(murbhip_sync(c));
     std::vector<float4> rec(c->slots), vel(c->slice);
+    std::vector<float> acc(closing_kick ? 3 * c->slice : 0);
     // positions: any shard holds all of them once its exchange has landed (sync above)
     {
         Shard& sh = c->shards[0];
@@ -1100,14 +1128,22 @@ int murbhip_download_state(murbhip_ctx* c, float* qx, float* qy, float* qz, floa
         for (Shard& sh : c->shards) {
             HIP_TRY(hipSetDevice(sh.device));
             HIP_TRY(hipMemcpy(vel.data(), sh.vel, vel.size() * sizeof(float4), hipMemcpyDeviceToHost));
+            if (closing_kick) HIP_TRY(hipMemcpy(acc.data(), sh.acc_out, acc.size() * sizeof(float), hipMemcpyDeviceToHost));
+            const float half = 0.5f * c->lf_last_dt;
             for (unsigned long k = 0; k < sh.count; ++k) {
                 const unsigned long ra = murb_rec_a(k >> 1);
                 const float* A = reinterpret_cast<const float*>(&vel[ra]);
                 const float* B = reinterpret_cast<const float*>(&vel[ra + MURB_TILE_PAIRS]);
                 const int h = (int)(k & 1);
-                if (vx) vx[sh.first + k] = A[h];
-                if (vy) vy[sh.first + k] = A[2 + h];
-                if (vz) vz[sh.first + k] = B[h];
+                float ox = A[h], oy = A[2 + h], oz = B[h];
+                if (closing_kick) {
+                    ox = half_kick(ox, acc[k], half);
+                    oy = half_kick(oy, acc[c->slice + k], half);
+                    oz = half_kick(oz, acc[2 * c->slice + k], half);
+                }
+                if (vx) vx[sh.first + k] = ox;
+                if (vy) vy[sh.first + k] = oy;
+                if (vz) vz[sh.first + k] = oz;
             }
         }
     }
@@ -1141,21 +1177,26 @@ int murbhip_step(murbhip_ctx* c, float dt)
 {
     if (!c) return MURBHIP_E_INVALID;
     if (!c->uploaded) return MURBHIP_E_STATE;
-    return enqueue_iteration(c, dt, 1);
+    RC_TRY(enqueue_iteration(c, dt, 1));
+    if (c->integrator == 1) { c->lf_half = true; c->lf_last_dt = dt; }
+    return 0;
 }
 
 int murbhip_steps(murbhip_ctx* c, float dt, int iterations)
 {
     if (!c || iterations < 0) return MURBHIP_E_INVALID;
     if (!c->uploaded) return MURBHIP_E_STATE;
-    for (int i = 0; i < iterations; ++i) RC_TRY(enqueue_iteration(c, dt, 1));
+    for (int i = 0; i < iterations; ++i) {
+        RC_TRY(enqueue_iteration(c, dt, 1));
+        if (c->integrator == 1) { c->lf_half = true; c->lf_last_dt = dt; }
+    }
     return 0;
 }
 
 int murbhip_integrate_host_acc(murbhip_ctx* c, const float* ax, const float* ay, const float* az, float dt)
 {
     if (!c || !ax || !ay || !az) return MURBHIP_E_INVALID;
-    if (!c->uploaded) return MURBHIP_E_STATE;
+    if (!c->uploaded || c->lf_half) return MURBHIP_E_STATE;   // a leapfrog run in flight has half-step velocities
     std::vector<float4> part(c->slice);
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
@@ -1165,7 +1206,7 @@ int murbhip_integrate_host_acc(murbhip_ctx* c, const float* ax, const float* ay,
             part[k] = make_float4(ax[sh.first + k], ay[sh.first + k], az[sh.first + k], 0.f);
         HIP_TRY(hipMemcpyAsync(sh.accp, part.data(), part.size() * sizeof(float4), hipMemcpyHostToDevice, sh.compute));
         HIP_TRY(hipStreamSynchronize(sh.compute));   // `part` is reused for the next shard
-        RC_TRY(enqueue_integrate(c, sh, 1, dt, 1));
+        RC_TRY(enqueue_integrate(c, sh, 1, dt, 1, nullptr, 0));
     }
     if (c->world > 1) RC_TRY(enqueue_exchange(c, c->cur ^ 1));
     c->cur ^= 1;
@@ -1210,6 +1251,27 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
     return 0;
 }
 
+int murbhip_moments(murbhip_ctx* c, double* out10)
+{
+    if (!c || !out10) return MURBHIP_E_INVALID;
+    if (!c->uploaded) return MURBHIP_E_STATE;
+    std::vector<float> q[3], v[3];
+    for (int k = 0; k < 3; ++k) { q[k].resize(c->n); v[k].resize(c->n); }
+    RC_TRY(murbhip_download_state(c, q[0].data(), q[1].data(), q[2].data(), v[0].data(), v[1].data(), v[2].data()));
+    double s[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (Shard& sh : c->shards)
+        for (unsigned long i = sh.first; i < sh.first + sh.count; ++i) {
+            const double m = c->host_mass[i];
+            const double x = q[0][i], y = q[1][i], z = q[2][i], ux = v[0][i], uy = v[1][i], uz = v[2][i];
+            s[0] += m * ux; s[1] += m * uy; s[2] += m * uz;
+            s[3] += m * (y * uz - z * uy); s[4] += m * (z * ux - x * uz); s[5] += m * (x * uy - y * ux);
+            s[6] += m * x; s[7] += m * y; s[8] += m * z;
+            s[9] += m;
+        }
+    std::memcpy(out10, s, sizeof s);
+    return 0;
+}
+
 int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
 {
     if (!c || !key) return MURBHIP_E_INVALID;
@@ -1217,6 +1279,11 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     if (k == "variant") { if (value < 0 || value > kNumVariants) return MURBHIP_E_INVALID; c->variant = (int)value; }
     else if (k == "jsplit") { if (value < 0 || value > kMaxParts / 2) return MURBHIP_E_INVALID; c->jsplit = (int)value; }
     else if (k == "overlap") { if (value < 0 || value > 2) return MURBHIP_E_INVALID; c->overlap = (int)value; }
+    else if (k == "integrator") {
+        if (value < 0 || value > 1) return MURBHIP_E_INVALID;
+        if (c->lf_half && value != c->integrator) return MURBHIP_E_STATE;   // half-step velocities on the device: upload first
+        c->integrator = (int)value;
+    }
     else if (k == "solo_shard") c->solo_shard = (int)value;
     else if (k == "force_exchange") {
         if (value && c->exchange == 1 && !c->shards[0].comm_rccl) return MURBHIP_E_STATE;

@@ -8,12 +8,15 @@
 
 #include "core/Bodies.hpp"
 #include "core/BodiesAllocator.hpp"
+#include "core/SimulationHistory.hpp"
 #include "implem/SimulationNBodyHIP.hpp"
+#include "implem/SimulationNBodyHIPTracking.hpp"
 
 namespace {
 struct Sim {
     std::string scheme;
     SimulationNBodyHIP<float> *sim = nullptr;
+    std::shared_ptr<SimulationHistory<double>> history;   // tracking sims only
 };
 void copyState(const dataSoA_t<float> &d, float *qx, float *qy, float *qz, float *vx, float *vy, float *vz, float *m,
                float *r)
@@ -70,6 +73,60 @@ void *murbhost_sim_create(unsigned long n, const char *scheme, float soft, float
     h->sim->setDt(dt);
     return h;
 }
+// --im hip+tracking (leapfrog = 0) / hip+leapfrog (1)
+void *murbhost_tracking_create(unsigned long n, const char *scheme, float soft, float dt, int leapfrog, int ndev,
+                               const int *devices, int exchange)
+{
+    auto *h = new Sim;
+    h->scheme = scheme;
+    h->history = std::make_shared<SimulationHistory<double>>();
+    HIPBodiesAllocator<float> alloc(n, h->scheme);
+    h->sim = new SimulationNBodyHIPTracking<float, double>(alloc, h->history, soft, leapfrog != 0,
+                                                           std::vector<int>(devices, devices + ndev), exchange);
+    h->sim->setDt(dt);
+    return h;
+}
+int murbhost_history_rows(void *p)
+{
+    auto *h = static_cast<Sim *>(p);
+    return h->history ? h->history->getNumIterations() : -1;
+}
+// rows entries each; centers as x0,y0,z0,x1,...
+void murbhost_history_get(void *p, double *energy, double *ang_momentum, double *centers)
+{
+    const auto &hist = *static_cast<Sim *>(p)->history;
+    for (int i = 0; i < hist.getNumIterations(); ++i) {
+        energy[i] = hist.getEnergyAt(i);
+        ang_momentum[i] = hist.getAngMomentumAt(i);
+        for (int k = 0; k < 3; ++k) centers[3 * i + k] = hist.getDensityCenterAt(i)[k];
+    }
+}
+// SimulationHistory alone (no device): fill `rows` rows and write the CSV.  0, or -1 if the file cannot be opened.
+int murbhost_history_csv(const char *path, int rows, const double *energy, const double *ang_momentum, const double *centers)
+{
+    SimulationHistory<double> hist(rows);
+    for (int i = 0; i < rows; ++i) {
+        hist.setEnergyAt(i, energy[i]);
+        hist.setAngMomentumAt(i, ang_momentum[i]);
+        hist.setDensityCenterAt(i, {centers[3 * i], centers[3 * i + 1], centers[3 * i + 2]});
+    }
+    try {
+        hist.saveMetricsToCSV(path);
+    } catch (const std::runtime_error &) {
+        return -1;
+    }
+    return 0;
+}
+int murbhost_sim_history_csv(void *p, const char *path)
+{
+    try {
+        static_cast<Sim *>(p)->history->saveMetricsToCSV(path);
+    } catch (const std::runtime_error &) {
+        return -1;
+    }
+    return 0;
+}
+
 void murbhost_sim_destroy(void *p)
 {
     auto *h = static_cast<Sim *>(p);

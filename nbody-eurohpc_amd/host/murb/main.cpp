@@ -7,17 +7,21 @@
 //
 // A maintainer of the reference adds the HIP path to the real driver with one branch in
 // createImplem() — see INTEGRATION.md; the branch below is that code.
+#include <cmath>
 #include <cstdlib>
 #include <iomanip>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
 
 #include "core/Bodies.hpp"
 #include "core/BodiesAllocator.hpp"
+#include "core/SimulationHistory.hpp"
 #include "implem/SimulationNBodyHIP.hpp"
+#include "implem/SimulationNBodyHIPTracking.hpp"
 #include "murbhip.h"
 #include "utils/ArgumentsReader.hpp"
 #include "utils/Perf.hpp"
@@ -35,6 +39,8 @@ std::string BodiesScheme = "galaxy";
 bool ShowGFlops = false;
 int NDevices = 0;        // --ngpu, hip+tile+multi only (0 = all visible)
 bool FreeRunning = false;   // --free: sync once at the end instead of once per iteration
+std::string MetricsFile;    // --csv: where hip+tracking / hip+leapfrog save their history
+std::shared_ptr<SimulationHistory<double>> History;
 
 // One row per command-line option: tag (as Arguments_reader wants it: "-im" is typed "--im"), name of
 // its value ("" = flag), required?, help text.  Same options as the reference (main.cpp:66-112) minus
@@ -63,12 +69,15 @@ static std::vector<Option> optionTable()
          "code implementation tag:\n"
          "\t\t\t - \"hip+tile\"        one MI355X, device-resident bodies\n"
          "\t\t\t - \"hip+tile+multi\"  bodies partitioned over --ngpu MI355X, RCCL position exchange\n"
+         "\t\t\t - \"hip+tracking\"    hip+tile + energy / angular momentum / centre of mass per iteration\n"
+         "\t\t\t - \"hip+leapfrog\"    hip+tracking with a kick-drift-kick leapfrog integrator\n"
          "\t\t\t ----"},
         {"-soft", "softeningFactor", false, "softening factor."},
         {"s", "bodies scheme", false, "bodies scheme (initial conditions can be \"galaxy\" or \"random\")."},
         {"-gf", "", false, "display the number of GFlop/s."},
         {"-ngpu", "nGpus", false, "number of GPUs for hip+tile+multi (default: all visible)."},
         {"-free", "", false, "free-running timing: one device sync at the end, not one per iteration."},
+        {"-csv", "file", false, "hip+tracking / hip+leapfrog: save the metrics history as CSV."},
     };
 }
 
@@ -98,6 +107,7 @@ static void argsReader(int argc, char **argv)
     if (given("-im")) ImplTag = reader.get_argument("-im");
     if (given("s")) BodiesScheme = reader.get_argument("s");
     if (given("-ngpu")) NDevices = stoi(reader.get_argument("-ngpu"));
+    if (given("-csv")) MetricsFile = reader.get_argument("-csv");
     if (given("-soft")) {
         Softening = stof(reader.get_argument("-soft"));
         if (Softening == 0.f) {   // the reference refuses it too (main.cpp:147-150): the self term would be 0/0
@@ -137,6 +147,11 @@ template <typename T> static SimulationNBodyHIP<T> *createImplem()
         HIPBodiesAllocator<T> hipAllocator(NBodies, BodiesScheme);
         return new SimulationNBodyHIP<T>(hipAllocator, Softening, devices, /*exchange: RCCL when distinct GPUs*/
                                          use <= visible ? 1 : 0);
+    }
+    if (ImplTag == "hip+tracking" || ImplTag == "hip+leapfrog") {   // shaped like main.cpp:245-261
+        HIPBodiesAllocator<T> hipAllocator(NBodies, BodiesScheme);
+        History = std::make_shared<SimulationHistory<double>>((int)NIterations);
+        return new SimulationNBodyHIPTracking<T, double>(hipAllocator, History, Softening, ImplTag == "hip+leapfrog");
     }
     std::cout << "Implementation '" << ImplTag << "' does not exist... Exiting." << std::endl;
     exit(-1);
@@ -205,6 +220,18 @@ int main(int argc, char **argv)
                << perfTotal.getGflops(simu->getFlopsPerIte() * (iIte - 1)) << " Gflop/s";
     std::cout << "Entire simulation took " << perfTotal.getElapsedTime() << " ms "
               << "(" << perfTotal.getFPS(iIte - 1) << " FPS" << gflops.str() << ")" << std::endl;
+
+    if (History && History->getNumIterations() > 1) {
+        const double e0 = History->getEnergyAt(0), e1 = History->getEnergyAt(History->getNumIterations() - 1);
+        std::cout << "Energy at the first / last tracked iteration: " << std::setprecision(9) << e0 << " / " << e1
+                  << " J (relative drift " << std::setprecision(3) << (e1 - e0) / (e0 != 0 ? std::abs(e0) : 1.0) << ")"
+                  << std::endl;
+    }
+    if (History && !MetricsFile.empty()) {
+        // the reference keeps this export commented out (main.cpp:400-401: "metrics.csv")
+        History->saveMetricsToCSV(MetricsFile);
+        std::cout << "Metrics saved to " << MetricsFile << std::endl;
+    }
 
     delete simu;
     return EXIT_SUCCESS;

@@ -62,6 +62,7 @@ def lib():
         L.murbhip_integrate_host_acc.argtypes = [C.c_void_p] + [_fp] * 3 + [C.c_float]
         L.murbhip_sync.argtypes = [C.c_void_p]
         L.murbhip_energy.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.murbhip_moments.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.murbhip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
         L.murbhip_get_info.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
         _lib = L
@@ -72,7 +73,7 @@ EXPORTS = ("murbhip_version murbhip_error_string murbhip_partition murbhip_slice
            "murbhip_schedule_items "
            "murbhip_device_count murbhip_create murbhip_create_sharded murbhip_unique_id murbhip_create_rank "
            "murbhip_destroy murbhip_upload murbhip_download_state murbhip_download_acc murbhip_compute_acc "
-           "murbhip_step murbhip_steps murbhip_integrate_host_acc murbhip_sync murbhip_energy murbhip_set_option "
+           "murbhip_step murbhip_steps murbhip_integrate_host_acc murbhip_sync murbhip_energy murbhip_moments murbhip_set_option "
            "murbhip_get_info").split()
 
 
@@ -192,6 +193,14 @@ class Simulation:
         _check(lib().murbhip_energy(self._h, C.byref(ke), C.byref(pe)), "murbhip_energy")
         return ke.value, pe.value
 
+    def moments(self):
+        """dict: linear momentum P, angular momentum L, mass-weighted position Mq (3 each) and mass M of
+        the caller's own bodies (fp64 host sums)."""
+        out = (C.c_double * 10)()
+        _check(lib().murbhip_moments(self._h, out), "murbhip_moments")
+        v = np.array(out[:])
+        return {"P": v[0:3], "L": v[3:6], "Mq": v[6:9], "M": float(v[9])}
+
     # -- tuning / facts
     def set_option(self, key, value):
         _check(lib().murbhip_set_option(self._h, key.encode(), int(value)), f"murbhip_set_option({key})")
@@ -253,6 +262,14 @@ def host_lib():
         H.murbhost_sim_allocated_bytes.argtypes = [C.c_void_p]
         H.murbhost_sim_state.argtypes = [C.c_void_p] + [_fp] * 8
         H.murbhost_sim_acc.argtypes = [C.c_void_p] + [_fp] * 3
+        _dp = C.POINTER(C.c_double)
+        H.murbhost_tracking_create.restype = C.c_void_p
+        H.murbhost_tracking_create.argtypes = [C.c_ulong, C.c_char_p, C.c_float, C.c_float, C.c_int, C.c_int,
+                                               C.POINTER(C.c_int), C.c_int]
+        H.murbhost_history_rows.argtypes = [C.c_void_p]
+        H.murbhost_history_get.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        H.murbhost_history_csv.argtypes = [C.c_char_p, C.c_int, _dp, _dp, _dp]
+        H.murbhost_sim_history_csv.argtypes = [C.c_void_p, C.c_char_p]
         _host = H
     return _host
 
@@ -278,15 +295,43 @@ def host_integrate(n, scheme, acc, dt, steps, on_device=False):
     return out
 
 
+def history_csv(path, energy, ang_momentum, centers):
+    """SimulationHistory<double>::saveMetricsToCSV on the given rows (host only; False if the file cannot be opened)."""
+    e, a = (np.ascontiguousarray(x, np.float64) for x in (energy, ang_momentum))
+    c = np.ascontiguousarray(centers, np.float64).reshape(-1)
+    dp = C.POINTER(C.c_double)
+    return host_lib().murbhost_history_csv(str(path).encode(), len(e), e.ctypes.data_as(dp), a.ctypes.data_as(dp),
+                                           c.ctypes.data_as(dp)) == 0
+
+
 class HostSim:
     """SimulationNBodyHIP<float> behind HIPBodiesAllocator<float> — the `--im hip+tile[+multi]` plugin."""
 
-    def __init__(self, n, scheme="galaxy", soft=2e8, dt=3600.0, devices=(0,), exchange="rccl"):
+    def __init__(self, n, scheme="galaxy", soft=2e8, dt=3600.0, devices=(0,), exchange="rccl", tracking=False,
+                 leapfrog=False):
+        """tracking=True: SimulationNBodyHIPTracking (`--im hip+tracking`; with leapfrog=True `hip+leapfrog`)."""
         arr = (C.c_int * len(devices))(*devices)
         self.H = host_lib()
-        self.h = self.H.murbhost_sim_create(n, scheme.encode(), soft, dt, len(devices), arr,
-                                            {"copy": 0, "rccl": 1}[exchange])
+        ex = {"copy": 0, "rccl": 1}[exchange]
+        if tracking or leapfrog:
+            self.h = self.H.murbhost_tracking_create(n, scheme.encode(), soft, dt, int(leapfrog), len(devices), arr, ex)
+        else:
+            self.h = self.H.murbhost_sim_create(n, scheme.encode(), soft, dt, len(devices), arr, ex)
         self.n = int(self.H.murbhost_sim_n(self.h))
+
+    def history(self):
+        """dict of the tracked metrics, one entry per computed iteration (tracking sims only)."""
+        rows = int(self.H.murbhost_history_rows(self.h))
+        if rows < 0:
+            raise RuntimeError("not a tracking simulation")
+        e, a, c = np.zeros(rows), np.zeros(rows), np.zeros(3 * rows)
+        dp = C.POINTER(C.c_double)
+        self.H.murbhost_history_get(self.h, e.ctypes.data_as(dp), a.ctypes.data_as(dp), c.ctypes.data_as(dp))
+        return {"energy": e, "ang_momentum": a, "density_center": c.reshape(rows, 3)}
+
+    def save_history_csv(self, path):
+        if self.H.murbhost_sim_history_csv(self.h, str(path).encode()) != 0:
+            raise RuntimeError(f"cannot open {path}")
 
     def step(self, iterations=1):
         self.H.murbhost_sim_step(self.h, iterations)

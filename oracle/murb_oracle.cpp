@@ -156,6 +156,42 @@ void oracle_simulate(int variant, unsigned long n, int iterations, float soft, f
     if (acc_out) std::memcpy(acc_out, a.data(), 3 * n * sizeof(float));
 }
 
+// Kick-drift-kick leapfrog as the reference STATES it (CUDABodies.cu:172-178):
+//     v_{n+1/2} = v_n + a_n dt/2 ;  x_{n+1} = x_n + v_{n+1/2} dt ;  v_{n+1} = v_{n+1/2} + a_{n+1} dt/2
+// in the one-force-per-step order of its own comment (:196-207), but with every a_n evaluated at x_n and
+// the closing half kick applied.  (The reference's kernels do neither: devLeapfrogMiddle publishes x_n
+// only after the force of iteration n has been taken at the previous positions, :262-268 with
+// SimulationNBodyCUDALeapfrog.cu:127-133, and devLeapfrogLast drops the last kick, :316-319 — so there
+// is no reference output to pin this against: PARITY UNPINNED, checked against this restatement and
+// through energy conservation only.)  fp32 kicks, the drift with the reference integrator's fp64
+// intermediate (Bodies.cpp:266-268); accelerations from the cpu+optim pair loop.
+void oracle_leapfrog(unsigned long n, int iterations, float soft, float dt, float* qx, float* qy, float* qz, float* vx,
+                     float* vy, float* vz, const float* m)
+{
+    if (iterations <= 0) return;
+    std::vector<float> a(3 * n);
+    float *ax = a.data(), *ay = ax + n, *az = ay + n;
+    for (int it = 0; it < iterations; ++it) {
+        oracle_accel_optim(n, qx, qy, qz, m, soft, ax, ay, az);
+        const FlushDenormalsLikeReference ftz;
+        const float h = it == 0 ? 0.5f * dt : 0.5f * (dt + dt);   // closing half of the last kick + opening half of this one
+        for (unsigned long i = 0; i < n; ++i) {
+            const float kx = ax[i] * h, ky = ay[i] * h, kz = az[i] * h;
+            vx[i] = vx[i] + kx; vy[i] = vy[i] + ky; vz[i] = vz[i] + kz;
+            qx[i] = (float)((double)qx[i] + (double)vx[i] * (double)dt);
+            qy[i] = (float)((double)qy[i] + (double)vy[i] * (double)dt);
+            qz[i] = (float)((double)qz[i] + (double)vz[i] * (double)dt);
+        }
+    }
+    oracle_accel_optim(n, qx, qy, qz, m, soft, ax, ay, az);
+    const FlushDenormalsLikeReference ftz;
+    const float h = 0.5f * dt;
+    for (unsigned long i = 0; i < n; ++i) {
+        const float kx = ax[i] * h, ky = ay[i] * h, kz = az[i] * h;
+        vx[i] = vx[i] + kx; vy[i] = vy[i] + ky; vz[i] = vz[i] + kz;
+    }
+}
+
 // fp32 full-N^2 direct sum for i in [i0, i1) in the device twin's operation order
 // (SimulationNBodyCUDATileFullDevice.cu:110-137: GM_j precomputed, FMA-shaped distance, f = GM_j*inv^3).
 // Used by the world_size>1 tests: each rank evaluates only its slice of i.

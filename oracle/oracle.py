@@ -56,6 +56,8 @@ def lib():
         L.oracle_integrate.argtypes = [C.c_ulong] + [_f] * 9 + [C.c_float]
         L.oracle_simulate.restype = None
         L.oracle_simulate.argtypes = [C.c_int, C.c_ulong, C.c_int, C.c_float, C.c_float] + [_f] * 7 + [C.c_void_p]
+        L.oracle_leapfrog.restype = None
+        L.oracle_leapfrog.argtypes = [C.c_ulong, C.c_int, C.c_float, C.c_float] + [_f] * 7
         L.oracle_accel_slice_f32.restype = None
         L.oracle_accel_slice_f32.argtypes = [C.c_ulong, C.c_ulong, C.c_ulong, _f, _f, _f, _f, C.c_float, _f, _f, _f]
         L.oracle_accel_f64.restype = None
@@ -140,6 +142,20 @@ def simulate(s, iterations, variant="cpu+optim", soft=SOFT, dt=DT):
     lib().oracle_simulate({"cpu+optim": 0, "cpu+naive": 1}[variant], n, iterations, soft, dt, s["qx"], s["qy"],
                           s["qz"], s["vx"], s["vy"], s["vz"], s["m"], acc.ctypes.data_as(C.c_void_p))
     return acc[:n], acc[n:2 * n], acc[2 * n:]
+
+
+def leapfrog(s, iterations, soft=SOFT, dt=DT):
+    """`iterations` kick-drift-kick steps in place, velocities synchronised at the end (parity unpinned:
+    see murb_oracle.cpp)."""
+    lib().oracle_leapfrog(len(s["qx"]), iterations, soft, dt, s["qx"], s["qy"], s["qz"], s["vx"], s["vy"], s["vz"], s["m"])
+
+
+def moments_f64(s):
+    """P = sum m v, L = sum m q x v, Mq = sum m q, M: fp64 (what murbhip_moments returns)."""
+    m = s["m"].astype(np.float64)
+    q = np.stack([s[k].astype(np.float64) for k in ("qx", "qy", "qz")])
+    v = np.stack([s[k].astype(np.float64) for k in ("vx", "vy", "vz")])
+    return {"P": (m * v).sum(1), "L": (m * np.cross(q.T, v.T).T).sum(1), "Mq": (m * q).sum(1), "M": float(m.sum())}
 
 
 def rel_err(test, ref):

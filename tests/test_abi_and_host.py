@@ -169,3 +169,21 @@ def test_half_ring_schedule_covers_every_pair_once(mh, n, world, split):
     assert off == (total_sub * total_sub - world * tb * split * split) // 2   # every other unordered pair exactly once
     if world > 1 and tb >= 2:
         assert max(counts) - min(counts) <= split * tb, counts     # balanced up to one block row
+
+
+def test_simulation_history_csv(mh, tmp_path):
+    """SimulationHistory<double>::saveMetricsToCSV: the reference's column names and max_digits10
+    precision (SimulationHistory.cpp:103-121), so the doubles survive the round trip exactly."""
+    rng = np.random.default_rng(3)
+    e, a, c = rng.normal(size=5) * 1e29, rng.uniform(size=5) * 1e34, rng.normal(size=(5, 3)) * 1e7
+    path = tmp_path / "metrics.csv"
+    assert mh.history_csv(path, e, a, c)
+    lines = path.read_text().splitlines()
+    assert lines[0] == "iteration,energy,ang_momentum,density_center_x,density_center_y,density_center_z"
+    assert len(lines) == 6
+    for i, line in enumerate(lines[1:]):
+        f = line.split(",")
+        assert int(f[0]) == i
+        assert [float(x) for x in f[1:]] == [e[i], a[i], c[i, 0], c[i, 1], c[i, 2]]
+    # an unwritable path is an error, not a silent no-op (the reference throws std::runtime_error)
+    assert not mh.history_csv(tmp_path / "no_such_dir" / "metrics.csv", e, a, c)

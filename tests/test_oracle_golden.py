@@ -106,3 +106,45 @@ def test_known_answer_facts(O):
     for w, p0, p1 in zip(whole, parts[0], parts[1]):
         assert np.array_equal(bits(w), bits(np.concatenate([p0, p1])))
     assert O.rel_err(whole, a).max() < 2e-6
+
+
+def test_leapfrog_restatement_properties(O):
+    """The kick-drift-kick restatement (murb_oracle.cpp: oracle_leapfrog) has no reference output to be
+    pinned against (the reference's gpu+leapfrog takes its forces at stale positions): PARITY UNPINNED.
+    What it must satisfy as a leapfrog: identical first drift to a hand-written step from the pinned
+    cpu+optim accelerations, energy and angular momentum conserved orders of magnitude better than the
+    reference's own update over the same 100 steps, and time reversibility."""
+    n = 2048
+    s0 = O.init_bodies(n, "galaxy")
+    # one step by hand from the (bit-pinned) cpu+optim accelerations
+    a0 = O.accel_optim(s0, SOFT)
+    h = np.float32(0.5) * DT
+    vh = {c: (s0["v" + c] + a0[i] * h).astype(np.float32) for i, c in enumerate("xyz")}
+    q1 = {c: (s0["q" + c].astype(np.float64) + vh[c].astype(np.float64) * float(DT)).astype(np.float32) for c in "xyz"}
+    s1 = {k: v.copy() for k, v in s0.items()}
+    O.leapfrog(s1, 1, SOFT, DT)
+    for c in "xyz":
+        assert np.array_equal(bits(s1["q" + c]), bits(q1[c]))
+    moved = dict(s0, qx=q1["x"], qy=q1["y"], qz=q1["z"])
+    a1 = O.accel_optim(moved, SOFT)
+    for i, c in enumerate("xyz"):
+        assert np.array_equal(bits(s1["v" + c]), bits((vh[c] + a1[i] * h).astype(np.float32)))
+    # conservation over 100 steps
+    e0 = sum(O.energy_f64(s0, SOFT))
+    L0 = O.moments_f64(s0)["L"]
+    lf = {k: v.copy() for k, v in s0.items()}
+    O.leapfrog(lf, 100, SOFT, DT)
+    eu = {k: v.copy() for k, v in s0.items()}
+    O.simulate(eu, 100, "cpu+optim", SOFT, DT)
+    drift_lf = abs(sum(O.energy_f64(lf, SOFT)) - e0) / abs(e0)
+    drift_eu = abs(sum(O.energy_f64(eu, SOFT)) - e0) / abs(e0)
+    assert drift_lf < 2e-5 and drift_eu > 50 * drift_lf, (drift_lf, drift_eu)
+    assert np.linalg.norm(O.moments_f64(lf)["L"] - L0) < 1e-5 * np.linalg.norm(L0)
+    assert np.linalg.norm(O.moments_f64(eu)["L"] - L0) > 1e-3 * np.linalg.norm(L0)
+    # reversibility: flip the velocities, run the same number of steps, arrive back (to fp32 noise)
+    for c in "xyz":
+        lf["v" + c] = -lf["v" + c]
+    O.leapfrog(lf, 100, SOFT, DT)
+    scale = np.abs(s0["qx"]).max()
+    for c in "xyz":
+        assert np.abs(lf["q" + c] - s0["q" + c]).max() < 2e-4 * scale

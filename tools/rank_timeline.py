@@ -21,8 +21,10 @@ if __name__ == "__main__":
         one.upload(murbhip.init_bodies(n, "galaxy")); one.steps(3600.0, 3); one.sync()
         t0 = time.perf_counter(); one.steps(3600.0, 20); one.sync(); base = (time.perf_counter() - t0) / 20 * 1e3
     print(f"N={n}: single GPU {base:.3f} ms/step")
+    splits = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
+    overlaps = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 1, 2]
     for w in (2, 4, 8):
-        for split in (0,):
-            for overlap in (0, 1, 2):
+        for split in splits:
+            for overlap in overlaps:
                 ms = solo_ms(n, w, 30, split, overlap)
                 print(f"  W={w} split={split} overlap={overlap}: rank 0 alone {ms:.3f} ms/step -> speedup x{base/ms:.2f} of ideal x{w}", flush=True)
