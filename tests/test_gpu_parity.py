@@ -593,8 +593,11 @@ def test_leapfrog_vs_restatement(gpu, O, scheme, n, devices):
     for k in ("qx", "qy", "qz"):
         assert np.abs(st[k] - ref[k]).max() <= TOL_POS * scale, k
     vscale = max(np.abs(ref[k]).max() for k in ("vx", "vy", "vz"))
+    # random scheme: cpu+optim's accelerations (the restatement's input) are themselves up to 2e-3 off for
+    # ~1 % of the bodies (flush-to-zero, see the module docstring), and velocities there are small
+    vtol = 2e-5 if scheme == "galaxy" else 2e-4
     for k in ("vx", "vy", "vz"):
-        assert np.abs(st[k] - ref[k]).max() <= 2e-5 * vscale, k
+        assert np.abs(st[k] - ref[k]).max() <= vtol * vscale, k
 
 
 def test_leapfrog_conserves_energy(gpu, O):
