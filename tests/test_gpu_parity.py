@@ -538,6 +538,29 @@ def test_bench_contract(gpu):
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and d["gpu_over_cpu"] > 1
 
 
+def test_bench_under_torchrun_one_rank(gpu):
+    """The launch line the driver uses for N > 1, with one rank: RCCL communicator from a broadcast unique id,
+    reduce-scatter + all-gather every step (force_exchange), and the run's own end-to-end check against a
+    plain single-GPU run of the same steps."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--bodies", "30000", "--steps", "20",
+           "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 1e12 and d["config"]["kernel_variant"] == 8
+    chk = d["rank_mode_check"]
+    assert chk["positions_identical_on_all_ranks"] and chk["finite"]
+    assert chk["max_position_diff_rel"] < 1e-5, chk
+
+
 # ---------------------------------------------------------------------------------------------------
 # SURVEY.md §8f rank 3 (rest) and rank 4: moments, the tracked-metrics plugin and the leapfrog integrator
 
