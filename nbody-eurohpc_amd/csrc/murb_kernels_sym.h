@@ -135,6 +135,9 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
     I = __builtin_amdgcn_readfirstlane(I);
     J = __builtin_amdgcn_readfirstlane(J);
     const float soft2 = a.soft2;
+#ifdef MURB_LAB_BEGIN     /* tools/sym_stamps.hip: per-workgroup time stamps (never defined in the product build) */
+    MURB_LAB_BEGIN();
+#endif
 
     // stage the J block: 2 layout tiles, A records to tileA, B records to tileB
     {
@@ -266,6 +269,9 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
             }
         }
     }
+#ifdef MURB_LAB_END
+    MURB_LAB_END();
+#endif
 }
 
 // Multi-rank schedule: which partial rows a rank has written for the bodies of each slice (up to
