@@ -113,14 +113,19 @@ __device__ __forceinline__ void murb_interact_sym(const murb_f2 xj, const murb_f
     ajz = __builtin_elementwise_fma(fj, dz, ajz);
 }
 
-// grid.x = T (T + 1) / 2 items; 256 threads.  MINW = waves per SIMD the register allocator must allow.
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSymArgs a)
+// grid.x = items; 64 * WAVES threads.  MINW = waves per SIMD the register allocator must allow.
+// WAVES = 4: one wave per SIMD and workgroup, four workgroups per CU.  WAVES = 8: two waves per SIMD and
+// workgroup, two workgroups per CU — an item takes half as long and a CU's last workgroup still has two
+// waves per SIMD to interleave (a lone wave reaches 61 % of the issue rate, tools/sym_stamps.hip), which
+// shortens the drain phase of short launches; per item it pays one more combine stage.
+template <int MINW, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const MurbSymArgs a)
 {
     constexpr int R = MURB_SYM_R;
+    constexpr int THREADS = 64 * WAVES;
     __shared__ float4 tileA[MURB_SYM_PAIRS];                    // {x0,x1,y0,y1} of the J block
     __shared__ float4 tileB[MURB_SYM_PAIRS];                    // {z0,z1,gm0,gm1}
-    __shared__ murb_f2 scratch[2][3][MURB_SYM_PAIRS];           // cross-wave combine of the j-side sums
+    __shared__ murb_f2 scratch[WAVES / 2][3][MURB_SYM_PAIRS];   // cross-wave combine of the j-side sums
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
     {
         const float4* src = a.rec + (unsigned long)J * (MURB_SYM_BLOCK / MURB_TILE_BODIES) * MURB_TILE_F4;
 #pragma unroll
-        for (int k = threadIdx.x; k < 2 * MURB_TILE_F4; k += 256) {
+        for (int k = threadIdx.x; k < 2 * MURB_TILE_F4; k += THREADS) {
             const int tile = k / MURB_TILE_F4, in = k % MURB_TILE_F4;
             const float4 v = src[k];
             if (in < MURB_TILE_PAIRS) tileA[tile * MURB_TILE_PAIRS + in] = v;
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
 
     const int split = a.split;
     const bool diagonal = (I / split) == J;
-    const int groups_per_wave = MURB_SYM_BLOCK / R / 4 / split;      // 64, 32 or 16
+    const int groups_per_wave = MURB_SYM_BLOCK / R / WAVES / split;  // WAVES = 4: 64, 32 or 16
     const unsigned int i_block_slot = (unsigned int)I * (unsigned int)(MURB_SYM_BLOCK / split);
     // the same item in the coordinates of the partial-sum planes
     const int Ip = I - a.plane_block0 * split, Jp = J - a.plane_block0;
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
 #pragma unroll 1
     for (int gk = 0; gk < groups_per_wave; ++gk) {
         asm volatile("" ::: "memory");   // keep the tile reads inside the loop: 64 VGPRs of hoisted j data spill
-        const int g = gk * 4 + wave;                            // interleave the waves over the block
+        const int g = gk * WAVES + wave;                        // interleave the waves over the block
         const unsigned int i_slot = i_block_slot + g * R;       // wave-uniform
         float xi[R], yi[R], zi[R], gi[R];
         {
@@ -227,35 +232,29 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
         a.part[(unsigned long)out_off + g * R] = total;
     }
 
-    // j side: combine the four waves in a fixed order (3+2 -> 1+0 -> 0), wave 0 writes partial row I
+    // j side: fold the waves pairwise in a fixed order (WAVES = 4: 3+2 -> 1+0 -> 0), wave 0 writes partial row I
     if (!diagonal) {
-        if (wave >= 2) {
 #pragma unroll
-            for (int p = 0; p < MURB_SYM_STEPS; ++p) {
-                scratch[wave - 2][0][p * 64 + lane] = ajx[p];
-                scratch[wave - 2][1][p * 64 + lane] = ajy[p];
-                scratch[wave - 2][2][p * 64 + lane] = ajz[p];
-            }
-        }
-        __syncthreads();
-        if (wave < 2) {
+        for (int half = WAVES / 2; half >= 1; half >>= 1) {
+            if (wave >= half && wave < 2 * half) {
 #pragma unroll
-            for (int p = 0; p < MURB_SYM_STEPS; ++p) {
-                ajx[p] += scratch[wave][0][p * 64 + lane];
-                ajy[p] += scratch[wave][1][p * 64 + lane];
-                ajz[p] += scratch[wave][2][p * 64 + lane];
+                for (int p = 0; p < MURB_SYM_STEPS; ++p) {
+                    scratch[wave - half][0][p * 64 + lane] = ajx[p];
+                    scratch[wave - half][1][p * 64 + lane] = ajy[p];
+                    scratch[wave - half][2][p * 64 + lane] = ajz[p];
+                }
             }
-        }
-        __syncthreads();
-        if (wave == 1) {
+            __syncthreads();
+            if (wave < half) {
 #pragma unroll
-            for (int p = 0; p < MURB_SYM_STEPS; ++p) {
-                scratch[0][0][p * 64 + lane] = ajx[p];
-                scratch[0][1][p * 64 + lane] = ajy[p];
-                scratch[0][2][p * 64 + lane] = ajz[p];
+                for (int p = 0; p < MURB_SYM_STEPS; ++p) {
+                    ajx[p] += scratch[wave][0][p * 64 + lane];
+                    ajy[p] += scratch[wave][1][p * 64 + lane];
+                    ajz[p] += scratch[wave][2][p * 64 + lane];
+                }
             }
+            if (half > 1) __syncthreads();
         }
-        __syncthreads();
         if (wave == 0) {
             const unsigned long base = (unsigned long)Jp * MURB_SYM_BLOCK;
             murb_f2* px = reinterpret_cast<murb_f2*>(a.part + ((unsigned long)0 * a.nrows + Ip) * a.row_stride + base);
@@ -263,9 +262,9 @@ __global__ __launch_bounds__(256, MINW) void murb_force_sym_kernel(const MurbSym
             murb_f2* pz = reinterpret_cast<murb_f2*>(a.part + ((unsigned long)2 * a.nrows + Ip) * a.row_stride + base);
 #pragma unroll
             for (int p = 0; p < MURB_SYM_STEPS; ++p) {
-                px[p * 64 + lane] = ajx[p] + scratch[0][0][p * 64 + lane];
-                py[p * 64 + lane] = ajy[p] + scratch[0][1][p * 64 + lane];
-                pz[p * 64 + lane] = ajz[p] + scratch[0][2][p * 64 + lane];
+                px[p * 64 + lane] = ajx[p];
+                py[p * 64 + lane] = ajy[p];
+                pz[p * 64 + lane] = ajz[p];
             }
         }
     }
