@@ -167,6 +167,8 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  *                    the one-sided kernel (1) otherwise.  1-6: one-sided variants, 7: persistent schedule
  *   "jsplit"         one-sided variants: number of j-chunks a body's sum is split into; variant 7:
  *                    scheduling rounds; variant 8: i-side sub-blocks per item (1, 2, 4, 8, 16).  0 = auto
+ *   "sym_waves"      variant 8: waves per workgroup, 4 or 8; 0 = auto (8, with `split` 8, on one GPU below
+ *                    45 000 bodies: a short launch drains faster; 4 otherwise)
  *   "profile"        1: bracket every force kernel with HIP events (read with murbhip_get_info)
  *   "overlap"        sharded/rank mode: 0 = no overlap; 1 (default) = the own-slice work brackets the
  *                    exchanges on the compute stream; 2 = the own-slice triangle runs on a second,

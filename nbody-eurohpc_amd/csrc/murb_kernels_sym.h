@@ -282,14 +282,60 @@ struct MurbSymRowRanges {
     int first[MURB_SYM_MAX_RANKS][3], count[MURB_SYM_MAX_RANKS][3], stride[MURB_SYM_MAX_RANKS][3];
 };
 
-// 256 threads = 64 consecutive slots x 4 row groups: row group g adds rows g, g+4, ... of every range
-// (fp64), the four partial sums are combined in a fixed order through LDS.  rr_ptr == null means one
-// rank owning everything (triangular schedule): the ranges follow from the slot's block B —
-// rows [0, split*B) hold j-side cells, rows split*J for J = B .. T-1 hold i-side cells.
-__global__ __launch_bounds__(256) void murb_sym_rowsum_kernel(const float* part, int nrows, unsigned int row_stride,
-                                                              const MurbSymRowRanges* rr_ptr, int split, float* send)
+// Row sum of one slot: 64 * MURB_ROWSUM_GROUPS threads = 64 consecutive slots x 16 row groups.  Row group g
+// adds rows g, g+16, ... of each of the (up to three) row ranges in fp64; the partial sums are combined in
+// a fixed order through LDS.  Returns true on the threads of row group 0, which then hold the totals.
+// (16 groups, not 4: at N = 30 000 the planes have 120-480 rows of only 30 720 slots, and 4 groups left
+// the kernel latency-bound at 1.7 TB/s.)
+#define MURB_ROWSUM_GROUPS 16
+#define MURB_ROWSUM_THREADS (64 * MURB_ROWSUM_GROUPS)
+__device__ __forceinline__ bool murb_sym_rowsum_slot(const float* part, int nrows, unsigned int row_stride,
+                                                     const int (&first)[3], const int (&count)[3], const int (&stride)[3],
+                                                     unsigned int s, int g, int lane,
+                                                     double (&red)[MURB_ROWSUM_GROUPS - 1][3][64], double (&total)[3])
 {
-    __shared__ double red[3][3][64];
+    double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int idx = g; idx < count[k]; idx += MURB_ROWSUM_GROUPS) {
+            const unsigned long r = (unsigned long)(first[k] + idx * stride[k]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] += (double)part[((unsigned long)c * nrows + r) * row_stride + s];
+        }
+    if (g > 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) red[g - 1][c][lane] = acc[c];
+    }
+    __syncthreads();
+    if (g != 0) return false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double t = acc[c];
+#pragma unroll
+        for (int k = 0; k < MURB_ROWSUM_GROUPS - 1; ++k) t += red[k][c][lane];
+        total[c] = t;
+    }
+    return true;
+}
+
+// One rank owning everything (triangular schedule): the row ranges of a slot follow from its block B —
+// rows [0, split*B) hold j-side cells, rows split*J for J = B .. T-1 hold i-side cells.
+__device__ __forceinline__ void murb_sym_triangular_ranges(unsigned int s, int nrows, int split, int (&first)[3],
+                                                           int (&count)[3], int (&stride)[3])
+{
+    const int B = (int)(s / MURB_SYM_BLOCK), T = nrows / split;
+    first[0] = 0; count[0] = split * B; stride[0] = 1;
+    first[1] = split * B; count[1] = T - B; stride[1] = split;
+    first[2] = 0; count[2] = 0; stride[2] = 1;
+}
+
+// rr_ptr == null: triangular single-rank mode, else the multi-rank row ranges per slice.
+__global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_kernel(const float* part, int nrows,
+                                                                              unsigned int row_stride,
+                                                                              const MurbSymRowRanges* rr_ptr, int split,
+                                                                              float* send)
+{
+    __shared__ double red[MURB_ROWSUM_GROUPS - 1][3][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const unsigned int s = blockIdx.x * 64 + lane;   // row_stride is a multiple of 1024: no partial block
     int first[3], count[3], stride[3];
@@ -301,31 +347,60 @@ __global__ __launch_bounds__(256) void murb_sym_rowsum_kernel(const float* part,
 #pragma unroll
         for (int k = 0; k < 3; ++k) { first[k] = rr_ptr->first[sl][k]; count[k] = rr_ptr->count[sl][k]; stride[k] = rr_ptr->stride[sl][k]; }
     } else {
-        const int B = (int)(s / MURB_SYM_BLOCK), T = nrows / split;
-        first[0] = 0; count[0] = split * B; stride[0] = 1;
-        first[1] = split * B; count[1] = T - B; stride[1] = split;
-        first[2] = 0; count[2] = 0; stride[2] = 1;
+        murb_sym_triangular_ranges(s, nrows, split, first, count, stride);
     }
-    double acc[3] = {0.0, 0.0, 0.0};
+    double total[3];
+    if (!murb_sym_rowsum_slot(part, nrows, row_stride, first, count, stride, s, g, lane, red, total)) return;
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-        for (int idx = g; idx < count[k]; idx += 4) {
-            const unsigned long r = (unsigned long)(first[k] + idx * stride[k]);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c] += (double)part[((unsigned long)c * nrows + r) * row_stride + s];
-        }
-    if (g > 0) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) red[g - 1][c][lane] = acc[c];
+    for (int c = 0; c < 3; ++c) send[((unsigned long)sl * 3 + c) * slice_slots + local] = (float)total[c];
+}
+
+// Single GPU: the triangular row sum and the state update in ONE launch (a dependent launch costs ~6 us, 3 %
+// of an N = 30 000 step).  One thread per SLOT here (the stand-alone murb_integrate_kernel has one per
+// pair): the two lanes of a pair read the same records and write disjoint halves.  Same arithmetic, same
+// rounding as murb_sym_rowsum_kernel followed by murb_integrate_kernel.
+__global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_integrate_kernel(const float* part, int nrows,
+                                                                                        unsigned int row_stride, int split,
+                                                                                        const MurbIntegrateArgs a)
+{
+#pragma clang fp contract(off)
+    __shared__ double red[MURB_ROWSUM_GROUPS - 1][3][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const unsigned int s = blockIdx.x * 64 + lane;
+    int first[3], count[3], stride[3];
+    murb_sym_triangular_ranges(s, nrows, split, first, count, stride);
+    double total[3];
+    if (!murb_sym_rowsum_slot(part, nrows, row_stride, first, count, stride, s, g, lane, red, total)) return;
+    const float ax = (float)total[0], ay = (float)total[1], az = (float)total[2];
+    a.acc_out[s] = ax;
+    a.acc_out[a.acc_stride + s] = ay;
+    a.acc_out[2u * a.acc_stride + s] = az;
+    if (!a.update_state || (int)s >= a.count) return;   // padding slots never change (both record buffers hold them)
+
+    const unsigned long ra = murb_rec_a((unsigned long)((unsigned int)a.i_first_slot + s) >> 1);
+    const unsigned long va = murb_rec_a((unsigned long)(s >> 1));
+    const int h = (int)(s & 1u);
+    const float4 A = a.rec_in[ra], B = a.rec_in[ra + MURB_TILE_PAIRS];
+    const float4 VA = a.vel[va], VB = a.vel[va + MURB_TILE_PAIRS];
+    float x = h ? A.y : A.x, y = h ? A.w : A.z, z = h ? B.y : B.x;
+    const float gm = h ? B.w : B.z;
+    float vx = h ? VA.y : VA.x, vy = h ? VA.w : VA.z, vz = h ? VB.y : VB.x;
+    const float dt = a.dt;
+    if (a.scheme == 1) {   // leapfrog kick-drift, see murb_integrate_kernel
+        const float k = a.kick_dt;
+        vx = murb_add_rounded(vx, murb_kick(ax, k)); vy = murb_add_rounded(vy, murb_kick(ay, k)); vz = murb_add_rounded(vz, murb_kick(az, k));
+        x = murb_drift(x, vx, 0.f, dt); y = murb_drift(y, vy, 0.f, dt); z = murb_drift(z, vz, 0.f, dt);
+    } else {
+        const float kx = murb_kick(ax, dt), ky = murb_kick(ay, dt), kz = murb_kick(az, dt);
+        x = murb_drift(x, vx, kx, dt); y = murb_drift(y, vy, ky, dt); z = murb_drift(z, vz, kz, dt);
+        vx = murb_add_rounded(vx, kx); vy = murb_add_rounded(vy, ky); vz = murb_add_rounded(vz, kz);
     }
-    __syncthreads();
-    if (g == 0) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double total = ((acc[c] + red[0][c][lane]) + red[1][c][lane]) + red[2][c][lane];
-            send[((unsigned long)sl * 3 + c) * slice_slots + local] = (float)total;
-        }
-    }
+    float* oa = reinterpret_cast<float*>(a.rec_out + ra);
+    float* ob = reinterpret_cast<float*>(a.rec_out + ra + MURB_TILE_PAIRS);
+    oa[h] = x; oa[2 + h] = y; ob[h] = z; ob[2 + h] = gm;
+    float* wa = reinterpret_cast<float*>(a.vel + va);
+    float* wb = reinterpret_cast<float*>(a.vel + va + MURB_TILE_PAIRS);
+    wa[h] = vx; wa[2 + h] = vy; wb[h] = vz;
 }
 
 // Reduce-scatter by peer reads (one process, several shards): out = sum over shards of their chunk.

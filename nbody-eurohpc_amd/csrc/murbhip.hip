@@ -191,6 +191,7 @@ struct murbhip_ctx {
     bool reduce_pending = false;   // peers may still be reading this context's reduce-scatter send buffers
     // options
     int variant = 0, jsplit = 0, profile = 0, overlap = 1;
+    int sym_waves = 0;        // pair-symmetric kernel: waves per workgroup, 0 = auto, 4 or 8
     int integrator = 0;       // 0 the reference's update (Bodies.cpp:260-278), 1 kick-drift-kick leapfrog
     bool lf_half = false;     // leapfrog: device velocities lag the positions by half a step of lf_last_dt
     float lf_last_dt = 0.f;
@@ -201,6 +202,7 @@ struct murbhip_ctx {
     int cu_count = 0, clock_mhz = 0;
     size_t device_mem = 0;     // bytes of HBM on the first device
     int last_parts = 0;
+    int plan_waves = 4;        // waves per workgroup of the current plan's pair-symmetric launches
     double interactions_per_launch = 0;
     int async_error = 0;
 };
@@ -213,6 +215,7 @@ struct Plan {
     bool persistent;                 // balanced persistent schedule (murb_force_persistent)
     bool symmetric;                  // pair-symmetric kernel (murb_force_sym_kernel)
     int split;                       // its i-side sub-blocks per block (1, 2, 4)
+    int waves;                       // ... and its waves per workgroup (4 or 8)
     MurbSchedule sched[2];           // [0] own slice (or everything), [1] the rest
 };
 
@@ -246,7 +249,7 @@ int launch_force(int variant, const MurbForceArgs& a, int i_slots, hipStream_t s
 constexpr int kNumVariants = 8;
 constexpr int kOneSidedVariant = 1;     // the persistent schedule (7) measured no faster: DESIGN.md §4.1
 constexpr int kPersistentVariant = 7;   // murb_force_persistent<8, 4, 4>
-constexpr int kSymmetricVariant = 8;    // murb_force_sym_kernel<4>
+constexpr int kSymmetricVariant = 8;    // murb_force_sym_kernel<4, 4 or 8>
 constexpr unsigned long kSymmetricMinBodies = 18432;   // below this the one-sided kernel wins (tools/sweep.py)
 constexpr int kRowsPerLaunch = kMaxParts / 2;
 
@@ -341,6 +344,10 @@ Plan make_plan(const murbhip_ctx* c)
         p.split = (c->jsplit == 1 || c->jsplit == 2 || c->jsplit == 4 || c->jsplit == 8 || c->jsplit == 16)
                       ? c->jsplit
                       : (items >= want ? 1 : (2 * items >= want ? 2 : 4));
+        // 8-wave workgroups (2 per SIMD, 2 workgroups per CU) drain faster at the end of a short launch
+        // (tools/waves_lab.hip: +4 % at N=30k with split 8, nothing from 60k up): used for one GPU below 45k
+        p.waves = (c->sym_waves == 4 || c->sym_waves == 8) ? c->sym_waves : ((c->world == 1 && c->n < 45000) ? 8 : 4);
+        if (c->jsplit == 0 && c->sym_waves == 0 && p.waves == 8) p.split = 8;
         p.persistent = false;
         p.parts_local = p.parts_remote = 0;
         return p;
@@ -418,11 +425,7 @@ int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
     if (p.symmetric) {   // one shard, no exchange: the whole triangle in one launch
         if (which != 0) return 0;
         RC_TRY(build_sym_schedule(c, sh, p.split));
-        RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_total));
-        hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slots / 64)), dim3(256), 0, sh.compute,
-                           sh.sym_part, sh.sym_split * (int)(c->slots / MURB_SYM_BLOCK), (unsigned int)c->slots,
-                           (const MurbSymRowRanges*)nullptr, sh.sym_split, sh.sym_recv);
-        RC_TRY(hip_rc(hipGetLastError()));
+        RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_total));   // its row sum is fused into the integrate launch
         c->interactions_per_launch = (double)c->n * (double)c->n;
         return 0;
     }
@@ -452,7 +455,6 @@ int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int updat
     MurbIntegrateArgs a{};
     a.scheme = scheme >= 0 ? scheme : c->integrator;
     a.kick_dt = leapfrog_kick(c, dt);
-    if (plan && plan->symmetric) a.acc_planes = sh.sym_recv;   // written by murb_sym_rowsum_kernel
     if (plan && plan->persistent) {
         a.group_bodies = 32;
         a.sched[0] = plan->sched[0];
@@ -470,6 +472,11 @@ int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int updat
     a.acc_stride = (unsigned int)c->slice;
     a.dt = dt;
     a.update_state = update_state;
+    if (plan && plan->symmetric) {   // one shard, triangular schedule: row sum of the partial planes + update in one launch
+        hipLaunchKernelGGL(murb_sym_rowsum_integrate_kernel, dim3((unsigned)(c->slots / 64)), dim3(MURB_ROWSUM_THREADS), 0, sh.compute,
+                           sh.sym_part, sh.sym_split * (int)(c->slots / MURB_SYM_BLOCK), (unsigned int)c->slots, sh.sym_split, a);
+        return hip_rc(hipGetLastError());
+    }
     const unsigned pairs = (unsigned)(c->slice / 2);
     hipLaunchKernelGGL(murb_integrate_kernel, dim3((pairs + 255) / 256), dim3(256), 0, sh.compute, a);
     return hip_rc(hipGetLastError());
@@ -636,7 +643,10 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
     sa.soft2 = c->soft2;
     const bool timed = stream == sh.compute;   // the profiling events live on the main compute stream
     if (timed) RC_TRY(prof_begin(c, sh));
-    hipLaunchKernelGGL(murb_force_sym_kernel<4>, dim3((unsigned)count), dim3(256), 0, stream, sa);
+    if (c->plan_waves == 8)
+        hipLaunchKernelGGL((murb_force_sym_kernel<4, 8>), dim3((unsigned)count), dim3(512), 0, stream, sa);
+    else
+        hipLaunchKernelGGL((murb_force_sym_kernel<4, 4>), dim3((unsigned)count), dim3(256), 0, stream, sa);
     RC_TRY(hip_rc(hipGetLastError()));
     if (timed) RC_TRY(prof_end(c, sh));
     return 0;
@@ -668,7 +678,7 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
             // the positions are still being gathered, then fills the gaps and the tail of the rectangles
             if (c->gather_pending || c->reduce_pending) HIP_TRY(hipStreamWaitEvent(sh.compute_low, sh.ev_integrated, 0));
             RC_TRY(enqueue_sym_launch(c, sh, 0, own, true, sh.compute_low));
-            hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slice / 64)), dim3(256), 0, sh.compute_low,
+            hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slice / 64)), dim3(MURB_ROWSUM_THREADS), 0, sh.compute_low,
                                sh.sym_tri, sh.sym_split * rows_own, (unsigned int)c->slice,
                                (const MurbSymRowRanges*)nullptr, sh.sym_split, sh.sym_tri_acc);
             RC_TRY(hip_rc(hipGetLastError()));
@@ -679,7 +689,7 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
         RC_TRY(enqueue_sym_launch(c, sh, own, sh.sym_items_total - own, false));
         if (c->exchange == 0 && c->reduce_pending)   // peer-read reduce: nobody may still be reading our send buffer
             for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.compute, peer.ev_reduced, 0));
-        hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slots / 64)), dim3(256), 0, sh.compute,
+        hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slots / 64)), dim3(MURB_ROWSUM_THREADS), 0, sh.compute,
                            sh.sym_part, sh.sym_split * rows_all, (unsigned int)c->slots, sh.sym_ranges, sh.sym_split,
                            sh.sym_send);
         RC_TRY(hip_rc(hipGetLastError()));
@@ -724,7 +734,7 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
             HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_tri, 0));
         } else {
             RC_TRY(enqueue_sym_launch(c, sh, t1, own - t1, true));
-            hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slice / 64)), dim3(256), 0, sh.compute,
+            hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slice / 64)), dim3(MURB_ROWSUM_THREADS), 0, sh.compute,
                                sh.sym_tri, sh.sym_split * rows_own, (unsigned int)c->slice,
                                (const MurbSymRowRanges*)nullptr, sh.sym_split, sh.sym_tri_acc);
             RC_TRY(hip_rc(hipGetLastError()));
@@ -761,6 +771,7 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
 {
     const Plan p = make_plan(c);
     c->last_parts = p.parts_local + p.parts_remote;
+    c->plan_waves = p.symmetric ? p.waves : 4;
     if (p.symmetric && (c->world > 1 || c->force_exchange)) return enqueue_iteration_sym_multi(c, p, dt, update_state);
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
@@ -1278,6 +1289,7 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     const std::string k(key);
     if (k == "variant") { if (value < 0 || value > kNumVariants) return MURBHIP_E_INVALID; c->variant = (int)value; }
     else if (k == "jsplit") { if (value < 0 || value > kMaxParts / 2) return MURBHIP_E_INVALID; c->jsplit = (int)value; }
+    else if (k == "sym_waves") { if (value != 0 && value != 4 && value != 8) return MURBHIP_E_INVALID; c->sym_waves = (int)value; }
     else if (k == "overlap") { if (value < 0 || value > 2) return MURBHIP_E_INVALID; c->overlap = (int)value; }
     else if (k == "integrator") {
         if (value < 0 || value > 1) return MURBHIP_E_INVALID;

@@ -390,8 +390,11 @@ def test_errors_are_reported(gpu):
 
 
 # ---- BASELINE.json sizes: size-independent properties -------------------------------------------
-@pytest.mark.parametrize("n,scheme", [(30000, "galaxy"), (200000, "galaxy"), (200000, "random"), (1000000, "galaxy")])
+@pytest.mark.parametrize("n,scheme", [(30000, "galaxy"), (200000, "galaxy"), (200000, "random"), (1000000, "galaxy"),
+                                      (2000003, "galaxy")])
 def test_full_size_properties(gpu, O, n, scheme):
+    """BASELINE.json's sizes (and one beyond them, odd: 47 GB of partial-sum planes) through properties that do
+    not need an O(N^2) oracle run."""
     s = O.init_bodies(n, scheme)
     with gpu.Simulation(n, soft=SOFT) as sim:
         sim.upload(s)
