@@ -118,7 +118,11 @@ __device__ __forceinline__ void murb_interact_sym(const murb_f2 xj, const murb_f
 // workgroup, two workgroups per CU — an item takes half as long and a CU's last workgroup still has two
 // waves per SIMD to interleave (a lone wave reaches 61 % of the issue rate, tools/sym_stamps.hip), which
 // shortens the drain phase of short launches; per item it pays one more combine stage.
-template <int MINW, int WAVES = 4>
+// ILOAD = 1 (what the library launches): the i bodies come through scalar loads (s_load_dwordx4 from the
+// constant address space, 4 per group) instead of 4 vector loads + 16 v_readfirstlane: 16 VALU issue slots
+// less per group of 576, +2.1 % at N=200k and +2.7 % at 30k, bit-identical results (tools/sload_lab.hip).
+// ILOAD = 0 keeps the vector-load form for that comparison.
+template <int MINW, int WAVES = 4, int ILOAD = 0>
 __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const MurbSymArgs a)
 {
     constexpr int R = MURB_SYM_R;
@@ -182,6 +186,22 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const 
         const int g = gk * WAVES + wave;                        // interleave the waves over the block
         const unsigned int i_slot = i_block_slot + g * R;       // wave-uniform
         float xi[R], yi[R], zi[R], gi[R];
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (ILOAD == 1) {
+            typedef const float4 __attribute__((address_space(4))) * murb_cf4p;
+            const murb_cf4p crec = (murb_cf4p)a.rec;
+            const unsigned long ra = murb_rec_a((unsigned long)(i_slot >> 1));
+#pragma unroll
+            for (int h = 0; h < R / 2; ++h) {
+                const float4 A = crec[ra + h];
+                const float4 B = crec[ra + h + MURB_TILE_PAIRS];
+                xi[2 * h] = A.x; xi[2 * h + 1] = A.y;
+                yi[2 * h] = A.z; yi[2 * h + 1] = A.w;
+                zi[2 * h] = B.x; zi[2 * h + 1] = B.y;
+                gi[2 * h] = B.z; gi[2 * h + 1] = B.w;
+            }
+        } else
+#endif
         {
             const unsigned long ra = murb_rec_a((unsigned long)(i_slot >> 1));
 #pragma unroll

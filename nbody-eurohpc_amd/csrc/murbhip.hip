@@ -644,9 +644,9 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
     const bool timed = stream == sh.compute;   // the profiling events live on the main compute stream
     if (timed) RC_TRY(prof_begin(c, sh));
     if (c->plan_waves == 8)
-        hipLaunchKernelGGL((murb_force_sym_kernel<4, 8>), dim3((unsigned)count), dim3(512), 0, stream, sa);
+        hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1>), dim3((unsigned)count), dim3(512), 0, stream, sa);
     else
-        hipLaunchKernelGGL((murb_force_sym_kernel<4, 4>), dim3((unsigned)count), dim3(256), 0, stream, sa);
+        hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1>), dim3((unsigned)count), dim3(256), 0, stream, sa);
     RC_TRY(hip_rc(hipGetLastError()));
     if (timed) RC_TRY(prof_end(c, sh));
     return 0;
