@@ -250,7 +250,7 @@ constexpr int kNumVariants = 8;
 constexpr int kOneSidedVariant = 1;     // the persistent schedule (7) measured no faster: DESIGN.md §4.1
 constexpr int kPersistentVariant = 7;   // murb_force_persistent<8, 4, 4>
 constexpr int kSymmetricVariant = 8;    // murb_force_sym_kernel<4, 4 or 8>
-constexpr unsigned long kSymmetricMinBodies = 18432;   // below this the one-sided kernel wins (tools/sweep.py)
+constexpr unsigned long kSymmetricMinBodies = 10240;   // below this the one-sided kernel wins (tools/sweep.py)
 constexpr int kRowsPerLaunch = kMaxParts / 2;
 
 int launch_persistent(const MurbForceArgs& a, const MurbSchedule& sc, hipStream_t s)
