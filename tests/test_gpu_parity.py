@@ -48,7 +48,7 @@ def gpu_acc(gpu, s, **opts):
 
 
 @pytest.mark.parametrize("scheme", ["galaxy", "random"])
-@pytest.mark.parametrize("n", [2048, 2049, 4000, 30000])
+@pytest.mark.parametrize("n", [2048, 2049, 4000, 12001, 30000])
 def test_acceleration_vs_oracles(gpu, O, scheme, n):
     s = O.init_bodies(n, scheme)
     a = gpu_acc(gpu, s)
@@ -166,6 +166,11 @@ def test_variants_and_jsplit_agree(gpu, O):
             a = gpu_acc(gpu, s, variant=variant, jsplit=jsplit)
             assert O.rel_err(a, truth).max() <= TOL_F64_MAX, (variant, jsplit)
             assert O.rel_err(a, base).max() <= 2e-6
+    # the pair-symmetric kernel's workgroup shapes and item sizes ("sym_waves" x "jsplit")
+    for waves in (4, 8):
+        for jsplit in (1, 4, 8, 16):
+            a = gpu_acc(gpu, s, variant=8, sym_waves=waves, jsplit=jsplit)
+            assert O.rel_err(a, truth).max() <= TOL_F64_MAX, (waves, jsplit)
     # bit-reproducible run to run (partial sums are added in a fixed order, no atomics)
     again = gpu_acc(gpu, s)
     assert all(np.array_equal(bits(x), bits(y)) for x, y in zip(base, again))
