@@ -169,6 +169,9 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  *                    scheduling rounds; variant 8: i-side sub-blocks per item (1, 2, 4, 8, 16).  0 = auto
  *   "sym_waves"      variant 8: waves per workgroup, 4 or 8; 0 = auto (8, with `split` 8, on one GPU below
  *                    45 000 bodies: a short launch drains faster; 4 otherwise)
+ *   "xcd_order"      variant 8: 0 (default) = j-major item order (round-robin dispatch then gives XCD x the i
+ *                    blocks x mod 8 of every j block); 1 = one contiguous run of items per XCD (measured:
+ *                    more L2 misses, same time; kept for the comparison)
  *   "profile"        1: bracket every force kernel with HIP events (read with murbhip_get_info)
  *   "overlap"        sharded/rank mode: 0 = no overlap; 1 (default) = the own-slice work brackets the
  *                    exchanges on the compute stream; 2 = the own-slice triangle runs on a second,

@@ -118,7 +118,33 @@ unsigned long slice_slots(unsigned long n, int world)
 //                           pair half a ring apart is shared and cut at a block boundary of the LOWER
 //                           rank's slice: the lower rank walks its first ceil(tb/2) blocks against all of
 //                           the other slice, the higher rank walks all of its own against the rest
-void sym_schedule_items(int world, int rank, int tb, int split, std::vector<int>& flat, int* own)
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup b of a launch runs on XCD b % 8) and every XCD
+// has its own L2.  The plain j-major table order is already XCD-friendly: the items of one j block are
+// consecutive, so XCD x gets the i blocks I = x mod 8 of EVERY j block — its L2 keeps one eighth of the
+// bodies (0.4 MB at N=200k) for the whole launch and only the 16 KiB j tile is fetched by all eight.
+// Option "xcd_order" = 1 instead cuts a launch's items into 8 contiguous runs, one per XCD (each XCD then
+// walks few j blocks but ALL i blocks): measured 35 % MORE L2 misses (FETCH_SIZE 216 vs 160 MiB per launch
+// at N=200k) and no time difference (tools/xcd_ab.py) — kept only for that comparison.
+constexpr int kXcds = 8;
+void xcd_interleave(std::vector<int>& flat, size_t first_item, size_t end_item)
+{
+    const size_t n = end_item - first_item;
+    if (n < 2 * kXcds) return;
+    std::vector<int> src(flat.begin() + 2 * first_item, flat.begin() + 2 * end_item);
+    // run x = source items [start(x), start(x + 1)); position p of the launch takes item p / 8 of run p % 8
+    auto start = [&](size_t x) { return x * n / kXcds; };
+    size_t p = 0;
+    for (size_t k = 0; p < n; ++k)
+        for (size_t x = 0; x < (size_t)kXcds && p < n; ++x) {
+            if (start(x) + k >= start(x + 1)) continue;   // this run is one item shorter
+            const size_t it = start(x) + k;
+            flat[2 * (first_item + p)] = src[2 * it];
+            flat[2 * (first_item + p) + 1] = src[2 * it + 1];
+            ++p;
+        }
+}
+
+void sym_schedule_items(int world, int rank, int tb, int split, std::vector<int>& flat, int* own, bool xcd_order = true)
 {
     const int W = world, r = rank, ts = tb * split;
     flat.clear();
@@ -138,6 +164,13 @@ void sym_schedule_items(int world, int rank, int tb, int split, std::vector<int>
                 flat.push_back(s * tb + j);
             }
     }
+    // the three launches of a step: first half of the own-slice triangle, second half, rectangles
+    if (!xcd_order) return;
+    const size_t n_own = (size_t)*own, n_all = flat.size() / 2;
+    if (W == 1) { xcd_interleave(flat, 0, n_all); return; }   // one launch
+    xcd_interleave(flat, 0, n_own / 2);
+    xcd_interleave(flat, n_own / 2, n_own);
+    xcd_interleave(flat, n_own, n_all);
 }
 
 // ------------------------------------------------------------------------------------ context
@@ -157,6 +190,7 @@ struct Shard {
     int2* sym_items = nullptr;
     int sym_items_own = 0, sym_items_total = 0;   // [0, own) = own-slice triangle, the rest need the gathered positions
     int sym_split = 0;                            // i-side sub-blocks per block the table was built for
+    int sym_xcd_order = -1;                       // ... and the item order ("xcd_order")
     bool sym_exchange_mode = false;               // ... and whether it was built for the exchange pipeline
     MurbSymRowRanges* sym_ranges = nullptr;
     float* sym_send = nullptr;   // [world][3][slice]
@@ -192,6 +226,7 @@ struct murbhip_ctx {
     // options
     int variant = 0, jsplit = 0, profile = 0, overlap = 1;
     int sym_waves = 0;        // pair-symmetric kernel: waves per workgroup, 0 = auto, 4 or 8
+    int xcd_order = 0;        // pair-symmetric kernel: 1 = item table interleaved into one run per XCD (measured worse)
     int integrator = 0;       // 0 the reference's update (Bodies.cpp:260-278), 1 kick-drift-kick leapfrog
     bool lf_half = false;     // leapfrog: device velocities lag the positions by half a step of lf_last_dt
     float lf_last_dt = 0.f;
@@ -547,7 +582,7 @@ int enqueue_exchange(murbhip_ctx* c, int buf)
 int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split)
 {
     const bool exchange_mode = c->world > 1 || c->force_exchange;
-    if (sh.sym_items && sh.sym_split == split && sh.sym_exchange_mode == exchange_mode) return 0;
+    if (sh.sym_items && sh.sym_split == split && sh.sym_exchange_mode == exchange_mode && sh.sym_xcd_order == c->xcd_order) return 0;
     if (sh.sym_items) {   // option changed: rebuild (the planes are re-zeroed because the row meaning changes)
         HIP_TRY(hipStreamSynchronize(sh.compute));
         hipFree(sh.sym_items); sh.sym_items = nullptr;
@@ -557,7 +592,8 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split)
     const int ts = tb * split;                          // i-side sub-blocks per slice
     std::vector<int> flat;
     int own = 0;
-    sym_schedule_items(W, r, tb, split, flat, &own);
+    sym_schedule_items(W, r, tb, split, flat, &own, c->xcd_order != 0);
+    sh.sym_xcd_order = c->xcd_order;
     std::vector<int2> items(flat.size() / 2);
     for (size_t k = 0; k < items.size(); ++k) items[k] = make_int2(flat[2 * k], flat[2 * k + 1]);
     MurbSymRowRanges rr{};
@@ -1289,6 +1325,7 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     const std::string k(key);
     if (k == "variant") { if (value < 0 || value > kNumVariants) return MURBHIP_E_INVALID; c->variant = (int)value; }
     else if (k == "jsplit") { if (value < 0 || value > kMaxParts / 2) return MURBHIP_E_INVALID; c->jsplit = (int)value; }
+    else if (k == "xcd_order") c->xcd_order = value ? 1 : 0;
     else if (k == "sym_waves") { if (value != 0 && value != 4 && value != 8) return MURBHIP_E_INVALID; c->sym_waves = (int)value; }
     else if (k == "overlap") { if (value < 0 || value > 2) return MURBHIP_E_INVALID; c->overlap = (int)value; }
     else if (k == "integrator") {
