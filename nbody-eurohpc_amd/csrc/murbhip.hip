@@ -144,7 +144,7 @@ void xcd_interleave(std::vector<int>& flat, size_t first_item, size_t end_item)
         }
 }
 
-void sym_schedule_items(int world, int rank, int tb, int split, std::vector<int>& flat, int* own, bool xcd_order = true)
+void sym_schedule_items(int world, int rank, int tb, int split, std::vector<int>& flat, int* own, bool xcd_order = false)
 {
     const int W = world, r = rank, ts = tb * split;
     flat.clear();
