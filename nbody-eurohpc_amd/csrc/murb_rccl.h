@@ -1,0 +1,58 @@
+// RCCL bound at run time (dlopen by soname): only the sharded / one-process-per-GPU modes need it, and a
+// Python host may already have loaded its own build of it.  Included by murbhip.hip only.
+#ifndef MURB_RCCL_H_
+#define MURB_RCCL_H_
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include "../../include/murbhip.h"
+
+namespace {
+
+typedef struct { char internal[MURBHIP_UNIQUE_ID_BYTES]; } rccl_id_t;
+typedef void* rccl_comm_t;
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(rccl_id_t*) = nullptr;
+    int (*CommInitRank)(rccl_comm_t*, int, rccl_id_t, int) = nullptr;
+    int (*CommInitAll)(rccl_comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(rccl_comm_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+constexpr int kRcclFloat = 7;   // ncclFloat32
+constexpr int kRcclSum = 0;     // ncclSum
+
+Rccl& rccl()
+{
+    static Rccl r;
+    if (r.lib || r.ok) return r;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) {
+        r.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return r;
+    r.GetUniqueId = (int (*)(rccl_id_t*))dlsym(r.lib, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(rccl_comm_t*, int, rccl_id_t, int))dlsym(r.lib, "ncclCommInitRank");
+    r.CommInitAll = (int (*)(rccl_comm_t*, int, const int*))dlsym(r.lib, "ncclCommInitAll");
+    r.CommDestroy = (int (*)(rccl_comm_t))dlsym(r.lib, "ncclCommDestroy");
+    r.AllGather = (int (*)(const void*, void*, size_t, int, rccl_comm_t, hipStream_t))dlsym(r.lib, "ncclAllGather");
+    r.ReduceScatter =
+        (int (*)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(r.lib, "ncclReduceScatter");
+    r.GroupStart = (int (*)())dlsym(r.lib, "ncclGroupStart");
+    r.GroupEnd = (int (*)())dlsym(r.lib, "ncclGroupEnd");
+    r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllGather && r.ReduceScatter && r.GroupStart &&
+           r.GroupEnd;
+    return r;
+}
+
+}  // namespace
+
+#endif

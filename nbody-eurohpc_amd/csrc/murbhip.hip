@@ -17,7 +17,6 @@
 //     high-priority stream (RCCL, bound lazily with dlopen, or peer copies/peer reads inside one
 //     process) under the two halves of the own-slice triangle (enqueue_iteration_sym_multi).
 #include <hip/hip_runtime.h>
-#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -30,6 +29,8 @@
 
 #include "../../include/murbhip.h"
 #include "murb_kernels_sym.h"
+#include "murb_rccl.h"
+#include "murb_schedule.h"
 
 namespace {
 
@@ -47,131 +48,6 @@ inline int nccl_rc(int r) { return r == 0 ? 0 : -(1000 + r); }
         const int rc_ = (expr);     \
         if (rc_ != 0) return rc_;   \
     } while (0)
-
-// ------------------------------------------------------------------------------------ lazy RCCL
-// Only the sharded/rank modes need RCCL, and a Python host may already have loaded its own build of
-// it: bind at run time by soname instead of linking.
-typedef struct { char internal[MURBHIP_UNIQUE_ID_BYTES]; } rccl_id_t;
-typedef void* rccl_comm_t;
-struct Rccl {
-    void* lib = nullptr;
-    int (*GetUniqueId)(rccl_id_t*) = nullptr;
-    int (*CommInitRank)(rccl_comm_t*, int, rccl_id_t, int) = nullptr;
-    int (*CommInitAll)(rccl_comm_t*, int, const int*) = nullptr;
-    int (*CommDestroy)(rccl_comm_t) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, rccl_comm_t, hipStream_t) = nullptr;
-    int (*ReduceScatter)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-    bool ok = false;
-};
-constexpr int kRcclFloat = 7;   // ncclFloat32
-constexpr int kRcclSum = 0;     // ncclSum
-
-Rccl& rccl()
-{
-    static Rccl r;
-    if (r.lib || r.ok) return r;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* nm : names) {
-        r.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        if (r.lib) break;
-    }
-    if (!r.lib) return r;
-    r.GetUniqueId = (int (*)(rccl_id_t*))dlsym(r.lib, "ncclGetUniqueId");
-    r.CommInitRank = (int (*)(rccl_comm_t*, int, rccl_id_t, int))dlsym(r.lib, "ncclCommInitRank");
-    r.CommInitAll = (int (*)(rccl_comm_t*, int, const int*))dlsym(r.lib, "ncclCommInitAll");
-    r.CommDestroy = (int (*)(rccl_comm_t))dlsym(r.lib, "ncclCommDestroy");
-    r.AllGather = (int (*)(const void*, void*, size_t, int, rccl_comm_t, hipStream_t))dlsym(r.lib, "ncclAllGather");
-    r.ReduceScatter =
-        (int (*)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(r.lib, "ncclReduceScatter");
-    r.GroupStart = (int (*)())dlsym(r.lib, "ncclGroupStart");
-    r.GroupEnd = (int (*)())dlsym(r.lib, "ncclGroupEnd");
-    r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
-    r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllGather && r.ReduceScatter && r.GroupStart &&
-           r.GroupEnd;
-    return r;
-}
-
-// ------------------------------------------------------------------------------------ partition (host only)
-void partition(unsigned long n, int world, int rank, unsigned long* first, unsigned long* count)
-{
-    const unsigned long base = n / (unsigned long)world, rem = n % (unsigned long)world;
-    const unsigned long r = (unsigned long)rank;
-    *count = base + (r < rem ? 1 : 0);
-    *first = r * base + std::min(r, rem);
-}
-
-unsigned long slice_slots(unsigned long n, int world)
-{
-    unsigned long first, count;
-    partition(n, world, 0, &first, &count);   // rank 0 always holds the largest slice
-    return murb_round_up_tile(std::max(count, 1ul));
-}
-
-// Items (i-side sub-block, j-side block) of rank r under the half-ring pair-symmetric schedule, in launch
-// order; the first `*own` entries are the own-slice triangle.  Host only (no HIP call): the rule that
-// every unordered body pair is evaluated by exactly one rank lives here and is unit-tested on the CPU.
-//   own slice x own slice : sub-block i against block j of the same slice, block(i) <= j
-//   own slice x slice r+d : d = 1 .. floor(W/2), all (sub-block, block) combinations; for even W the slice
-//                           pair half a ring apart is shared and cut at a block boundary of the LOWER
-//                           rank's slice: the lower rank walks its first ceil(tb/2) blocks against all of
-//                           the other slice, the higher rank walks all of its own against the rest
-// Workgroups are dealt to the 8 XCDs round-robin (workgroup b of a launch runs on XCD b % 8) and every XCD
-// has its own L2.  The plain j-major table order is already XCD-friendly: the items of one j block are
-// consecutive, so XCD x gets the i blocks I = x mod 8 of EVERY j block — its L2 keeps one eighth of the
-// bodies (0.4 MB at N=200k) for the whole launch and only the 16 KiB j tile is fetched by all eight.
-// Option "xcd_order" = 1 instead cuts a launch's items into 8 contiguous runs, one per XCD (each XCD then
-// walks few j blocks but ALL i blocks): measured 35 % MORE L2 misses (FETCH_SIZE 216 vs 160 MiB per launch
-// at N=200k) and no time difference (tools/xcd_ab.py) — kept only for that comparison.
-constexpr int kXcds = 8;
-void xcd_interleave(std::vector<int>& flat, size_t first_item, size_t end_item)
-{
-    const size_t n = end_item - first_item;
-    if (n < 2 * kXcds) return;
-    std::vector<int> src(flat.begin() + 2 * first_item, flat.begin() + 2 * end_item);
-    // run x = source items [start(x), start(x + 1)); position p of the launch takes item p / 8 of run p % 8
-    auto start = [&](size_t x) { return x * n / kXcds; };
-    size_t p = 0;
-    for (size_t k = 0; p < n; ++k)
-        for (size_t x = 0; x < (size_t)kXcds && p < n; ++x) {
-            if (start(x) + k >= start(x + 1)) continue;   // this run is one item shorter
-            const size_t it = start(x) + k;
-            flat[2 * (first_item + p)] = src[2 * it];
-            flat[2 * (first_item + p) + 1] = src[2 * it + 1];
-            ++p;
-        }
-}
-
-void sym_schedule_items(int world, int rank, int tb, int split, std::vector<int>& flat, int* own, bool xcd_order = false)
-{
-    const int W = world, r = rank, ts = tb * split;
-    flat.clear();
-    for (int j = 0; j < tb; ++j)
-        for (int i = 0; i < (j + 1) * split; ++i) { flat.push_back(r * ts + i); flat.push_back(r * tb + j); }
-    *own = (int)flat.size() / 2;
-    for (int d = 1; d <= W / 2; ++d) {
-        const int s = (r + d) % W;
-        if (s == r) continue;
-        const bool shared = (W % 2 == 0) && d == W / 2;
-        const int lo = std::min(r, s), hb = (tb + 1) / 2;
-        for (int i = 0; i < ts; ++i)
-            for (int j = 0; j < tb; ++j) {
-                // i: OWN sub-blocks (walked, i side); j: the other slice's blocks (LDS resident, j side)
-                if (shared && !((r == lo) ? (i / split < hb) : (j >= hb))) continue;
-                flat.push_back(r * ts + i);
-                flat.push_back(s * tb + j);
-            }
-    }
-    // the three launches of a step: first half of the own-slice triangle, second half, rectangles
-    if (!xcd_order) return;
-    const size_t n_own = (size_t)*own, n_all = flat.size() / 2;
-    if (W == 1) { xcd_interleave(flat, 0, n_all); return; }   // one launch
-    xcd_interleave(flat, 0, n_own / 2);
-    xcd_interleave(flat, n_own / 2, n_own);
-    xcd_interleave(flat, n_own, n_all);
-}
 
 // ------------------------------------------------------------------------------------ context
 struct Shard {
