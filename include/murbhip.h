@@ -94,7 +94,9 @@ int murbhip_create_sharded(murbhip_ctx** out, unsigned long n, float soft, float
 
 /* One process per GPU (torchrun / mpirun style).  Rank 0 calls murbhip_unique_id() and ships the
  * 128 bytes to every rank out of band; every rank then calls murbhip_create_rank().  Takes the place
- * of the reference's lazy MPI_Init/Comm_rank/Comm_size (SimulationNBodyMultiNode.cpp:62-73). */
+ * of the reference's lazy MPI_Init/Comm_rank/Comm_size (SimulationNBodyMultiNode.cpp:62-73).
+ * RCCL is bound at run time (librccl.so.1 by soname, so a host that already loaded RCCL shares it);
+ * the environment variable MURBHIP_RCCL_LIBRARY names a specific library file to bind instead. */
 int murbhip_unique_id(void* id_out /* MURBHIP_UNIQUE_ID_BYTES */);
 int murbhip_create_rank(murbhip_ctx** out, unsigned long n, float soft, float g, int device, int rank, int world,
                         const void* unique_id);

@@ -4,6 +4,8 @@
 #define MURB_RCCL_H_
 
 #include <dlfcn.h>
+
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include "../../include/murbhip.h"
@@ -32,10 +34,14 @@ Rccl& rccl()
 {
     static Rccl r;
     if (r.lib || r.ok) return r;
+    // MURBHIP_RCCL_LIBRARY: path of the library to bind instead (a site build of RCCL; the tests' mock).
+    // RTLD_LOCAL for it: its ncclXxx symbols must not shadow those of an RCCL the host already loaded.
+    const char* override_path = std::getenv("MURBHIP_RCCL_LIBRARY");
+    if (override_path && *override_path) r.lib = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* nm : names) {
-        r.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
         if (r.lib) break;
+        r.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!r.lib) return r;
     r.GetUniqueId = (int (*)(rccl_id_t*))dlsym(r.lib, "ncclGetUniqueId");

@@ -1,0 +1,114 @@
+"""GPU: the one-process-per-GPU path (murbhip_create_rank with rank > 0 and world > 1) with SEVERAL PROCESSES
+ON ONE GPU.  Real RCCL refuses two ranks on one device, so the collectives come from a stand-in library
+(tests/helpers/rccl_mock.cpp, bound through MURBHIP_RCCL_LIBRARY) that has the same entry points and
+argument meaning and moves the data through shared host memory.  What this exercises that nothing else on
+a one-GPU box can: every rank-mode code path of csrc/murbhip.hip for rank != 0 — slice offsets of the
+in-place all-gather, the reduce-scatter chunk layout, the row ranges of the half-ring schedule, and that
+all ranks issue their collectives in the same order (a mismatch deadlocks here exactly as it would on
+eight GPUs; the test then fails on its timeout)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+MOCK = os.path.join(ROOT, "tests", "helpers", "_build", "librccl_mock.so")
+WORKER = os.path.join(ROOT, "tests", "_rank_worker.py")
+SOFT, DT = np.float32(2e8), np.float32(3600.0)
+
+
+def run_ranks(tmp_path, world, n, steps, variant, overlap=1, jsplit=0, integrator=0):
+    assert os.path.exists(MOCK), "build it: make -C tests/helpers (done by __graft_entry__.build())"
+    env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK)
+    # the unique id comes from the same library the ranks will bind: ask a throw-away process for it
+    uid = subprocess.run([sys.executable, "-c",
+                          f"import sys; sys.path.insert(0, {os.path.join(ROOT, 'nbody-eurohpc_amd')!r}); import murbhip; "
+                          "print(murbhip.unique_id().hex())"], env=env, capture_output=True, text=True, timeout=120)
+    assert uid.returncode == 0, uid.stderr
+    uidhex = uid.stdout.strip()
+    assert bytes.fromhex(uidhex)[:8] == b"MOCKRCCL"
+    procs = []
+    for r in range(world):
+        out = tmp_path / f"rank{r}.npz"
+        procs.append((out, subprocess.Popen([sys.executable, WORKER, str(r), str(world), uidhex, str(n), str(steps), str(variant),
+                                             str(overlap), str(jsplit), str(integrator), str(out)], env=env,
+                                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    results, failed = [], []
+    for out, p in procs:
+        try:
+            _, err = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            for _, q in procs:
+                q.kill()                      # exactly the processes started here
+            pytest.fail("ranks did not finish: collective order mismatch or a dead rank")
+        if p.returncode != 0:
+            failed.append(err[-1500:])
+    assert not failed, failed
+    for out, _ in procs:
+        results.append(dict(np.load(out)))
+    return results
+
+
+@pytest.mark.parametrize("world,n,variant,overlap,jsplit", [
+    (2, 9000, 1, 1, 0),      # one-sided kernel, all-gather only
+    (2, 9000, 8, 1, 0),      # half-ring schedule, even world (shared slice pair)
+    (3, 9000, 8, 1, 2),      # odd world
+    (4, 20000, 8, 0, 0),     # no overlap
+    (4, 20000, 8, 1, 4),
+    (5, 12000, 8, 2, 1),     # overlap mode 2, odd world
+])
+def test_ranks_match_single_gpu(gpu, O, tmp_path, world, n, variant, overlap, jsplit):
+    steps = 3
+    ranks = run_ranks(tmp_path, world, n, steps, variant, overlap, jsplit)
+    s = O.init_bodies(n, "galaxy")
+    with gpu.Simulation(n, soft=SOFT) as one:
+        one.upload(s)
+        one.compute_acc(); one.sync()
+        acc = one.acc()
+        one.steps(DT, steps); one.sync()
+        ref = one.state()
+        ke, pe = one.energy()
+    scale = max(np.abs(ref[k]).max() for k in ("qx", "qy", "qz"))
+    vscale = max(np.abs(ref[k]).max() for k in ("vx", "vy", "vz"))
+    covered = np.zeros(n, bool)
+    for r, d in enumerate(ranks):
+        assert int(d["used_variant"]) == variant
+        f, c = int(d["first"]), int(d["count"])
+        covered[f:f + c] = True
+        # every rank holds ALL gathered positions
+        for k in ("qx", "qy", "qz"):
+            assert np.abs(d[k] - ref[k]).max() <= 2e-6 * scale, (r, k)
+        # ... and the velocities and accelerations of its own bodies
+        for k in ("vx", "vy", "vz"):
+            assert np.abs(d[k][f:f + c] - ref[k][f:f + c]).max() <= 2e-5 * vscale, (r, k)
+        own = tuple(d[k][f:f + c] for k in ("ax", "ay", "az"))
+        assert O.rel_err(own, tuple(a[f:f + c] for a in acc)).max() <= 2e-6, r
+    assert covered.all()
+    # positions are bit-identical on all ranks (they all received the same bytes)
+    for d in ranks[1:]:
+        for k in ("qx", "qy", "qz"):
+            assert np.array_equal(d[k].view(np.uint32), ranks[0][k].view(np.uint32))
+    # energy: each rank reports its own bodies' share
+    assert abs(sum(float(d["ke"]) for d in ranks) - ke) <= 1e-5 * abs(ke)
+    assert abs(sum(float(d["pe"]) for d in ranks) - pe) <= 1e-5 * abs(pe)
+
+
+def test_ranks_leapfrog(gpu, O, tmp_path):
+    """The closing half kick on read-out is a collective in rank mode (one more force evaluation on every rank)."""
+    world, n, steps = 3, 9000, 4
+    ranks = run_ranks(tmp_path, world, n, steps, 8, integrator=1)
+    ref = O.init_bodies(n, "galaxy")
+    O.leapfrog(ref, steps, SOFT, DT)
+    scale = max(np.abs(ref[k]).max() for k in ("qx", "qy", "qz"))
+    vscale = max(np.abs(ref[k]).max() for k in ("vx", "vy", "vz"))
+    for d in ranks:
+        f, c = int(d["first"]), int(d["count"])
+        for k in ("qx", "qy", "qz"):
+            assert np.abs(d[k] - ref[k]).max() <= 2e-6 * scale
+        for k in ("vx", "vy", "vz"):
+            assert np.abs(d[k][f:f + c] - ref[k][f:f + c]).max() <= 2e-5 * vscale
