@@ -112,3 +112,28 @@ def test_ranks_leapfrog(gpu, O, tmp_path):
             assert np.abs(d[k] - ref[k]).max() <= 2e-6 * scale
         for k in ("vx", "vy", "vz"):
             assert np.abs(d[k][f:f + c] - ref[k][f:f + c]).max() <= 2e-5 * vscale
+
+
+@pytest.mark.parametrize("world,n", [(2, 40000), (4, 120000)])
+def test_bench_py_with_several_ranks(gpu, world, n):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one process per rank), with
+    the ranks sharing GPU 0: its own process group on gloo and the library's collectives on the stand-in
+    (real RCCL refuses both on one device).  Checks the N > 1 flow the driver depends on: unique-id broadcast,
+    rank-mode context per rank, max-over-ranks timing, ONE JSON line from rank 0, and the run's own check of
+    the multi-rank result against a single-GPU run."""
+    import json
+    env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK, MURB_BENCH_BACKEND="gloo", MURB_BENCH_SHARE_GPU="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(29560 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--bodies",
+           str(n), "--steps", "10", "--warmup", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["config"]["kernel_variant"] == 8
+    assert abs(d["value"] - float(n) ** 2 * 10 / (d["ms_per_step"] * 10e-3)) / d["value"] < 1e-6
+    chk = d["rank_mode_check"]
+    assert chk["positions_identical_on_all_ranks"] and chk["finite"] and chk["max_position_diff_rel"] < 1e-4, chk
+    assert "cpu_baseline" not in d      # rank 0 at N = 1 only
