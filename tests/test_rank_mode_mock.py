@@ -57,7 +57,8 @@ def run_ranks(tmp_path, world, n, steps, variant, overlap=1, jsplit=0, integrato
 @pytest.mark.parametrize("world,n,variant,overlap,jsplit", [
     (2, 9000, 1, 1, 0),      # one-sided kernel, all-gather only
     (2, 9000, 8, 1, 0),      # half-ring schedule, even world (shared slice pair)
-    (3, 9000, 8, 1, 2),      # odd world
+    (3, 9001, 8, 1, 2),      # odd world, bodies not divisible by it (ranks own 3001 / 3000 / 3000)
+    (4, 10003, 1, 0, 0),     # one-sided, ragged partition
     (4, 20000, 8, 0, 0),     # no overlap
     (4, 20000, 8, 1, 4),
     (5, 12000, 8, 2, 1),     # overlap mode 2, odd world
