@@ -83,3 +83,33 @@ def test_simd_and_omp_are_speed_baselines_only(ref):
         assert 1e-5 < e.max() < 5e-3
         r.close()
     opt.close()
+
+
+def test_file_scheme_matches_reference(ref, tmp_path, monkeypatch):
+    """Any scheme other than galaxy/random reads `milkyway_andromeda.tab` from the working directory
+    (Bodies.cpp:14-25, 83-153; the file itself is not in the reference repository): one body per non-empty
+    line, rescaled by component galaxy.  A synthetic 70 000-line file reaches five of the six index ranges;
+    the product's host mirror must produce the reference's arrays bit for bit, and both must refuse a
+    missing file."""
+    import murbhip
+    rng = np.random.default_rng(11)
+    n = 70000
+    rows = rng.normal(size=(n, 7)).astype(np.float32)
+    rows[:, 0] = np.abs(rows[:, 0]) * 1e-5
+    with open(tmp_path / "milkyway_andromeda.tab", "w") as f:
+        for k, r in enumerate(rows):
+            f.write(" ".join(f"{x:.9g}" for x in r) + "\n")
+            if k % 1000 == 0:
+                f.write("\n")                      # empty lines are skipped
+    monkeypatch.chdir(tmp_path)
+    r = ref.RefSim("cpu+naive", 5, "collision")    # n is replaced by the number of lines
+    assert r.n == n and r.padding == 0
+    want = r.state()
+    r.close()
+    got = murbhip.init_bodies(n, "collision")
+    for k in ref.FIELDS:
+        assert np.array_equal(bits(want[k]), bits(got[k])), k
+    assert np.all(got["r"] == np.float32(1e5))
+    # Milky Way ranges use 4.5e10 / 4.0 / 220, Andromeda ranges 9.4e10 / 6.0 / 260
+    assert got["m"][0] == np.float32(np.float64(rows[0, 0]) * 4.5e10) and got["qx"][20000] == np.float32(np.float64(rows[20000, 1]) * 6.0)
+    assert got["vz"][66000] == np.float32(np.float64(rows[66000, 6]) * 260)
