@@ -187,3 +187,13 @@ def test_simulation_history_csv(mh, tmp_path):
         assert [float(x) for x in f[1:]] == [e[i], a[i], c[i, 0], c[i, 1], c[i, 2]]
     # an unwritable path is an error, not a silent no-op (the reference throws std::runtime_error)
     assert not mh.history_csv(tmp_path / "no_such_dir" / "metrics.csv", e, a, c)
+
+
+def test_simulation_history_container_semantics():
+    """The host cases of the reference's test_SimulationHistory.cu:12-77 restated for host/core/SimulationHistory.hpp
+    (a small C++ program, tests/helpers/history_selftest.cpp)."""
+    exe = os.path.join(ROOT, "tests", "helpers", "_build", "history_selftest")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "helpers"), "_build/history_selftest"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout
