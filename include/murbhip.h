@@ -125,7 +125,9 @@ int murbhip_download_acc(murbhip_ctx* ctx, float* ax, float* ay, float* az);
 
 /* a_i = sum_j G m_j (q_j - q_i) / (|q_j - q_i|^2 + soft^2)^(3/2) for the current positions, no
  * integration.  Enqueue only.  (computeBodiesAcceleration: SimulationNBodyOptim.cpp:34-94,
- * device twin SimulationNBodyCUDATileFullDevice.cu:53-153.) */
+ * device twin SimulationNBodyCUDATileFullDevice.cu:53-153.)  The result is remembered: a second call
+ * without a state change in between costs nothing, and a murbhip_step() that follows directly reuses
+ * the forces instead of evaluating them again (one shard; bit-identical either way). */
 int murbhip_compute_acc(murbhip_ctx* ctx);
 
 /* One iteration = force + position/velocity update [+ position exchange].  Enqueue only.
@@ -148,8 +150,8 @@ int murbhip_sync(murbhip_ctx* ctx);
  * G m_i m_j / sqrt(r_ij^2 + soft^2) — the per-iteration metric of the reference's gpu+tracking
  * implementation (SimulationNBodyCUDAPropertyTracking.cu:217-304, summed there with cub).  One N^2
  * potential sweep on the device, the O(N) sum in fp64 on the host; waits for enqueued steps.  In rank
- * mode the values cover the caller's own bodies only (sum them over ranks).  The potential sweep reuses
- * the acceleration output: murbhip_download_acc() returns it (x plane) until the next step. */
+ * mode the values cover the caller's own bodies only (sum them over ranks).  The accelerations of the
+ * last evaluation (murbhip_download_acc) are left alone. */
 int murbhip_energy(murbhip_ctx* ctx, double* kinetic, double* potential);
 
 /* First moments of the current state, fp64 sums on the host over the caller's own bodies:

@@ -61,6 +61,7 @@ struct Shard {
     float4* vel = nullptr;
     float4* accp = nullptr;
     float* acc_out = nullptr;
+    float* phi_out = nullptr;    // murbhip_energy's potential sweep (same shape as acc_out), allocated on first use
     float* sym_part = nullptr;   // pair-symmetric kernel: 3 planes of (slots/1024) rows, allocated on first use
     // multi-rank pair-symmetric schedule (half ring): item table, row ranges, reduce-scatter buffers
     int2* sym_items = nullptr;
@@ -105,6 +106,10 @@ struct murbhip_ctx {
     int xcd_order = 0;        // pair-symmetric kernel: 1 = item table interleaved into one run per XCD (measured worse)
     int integrator = 0;       // 0 the reference's update (Bodies.cpp:260-278), 1 kick-drift-kick leapfrog
     bool lf_half = false;     // leapfrog: device velocities lag the positions by half a step of lf_last_dt
+    // acceleration cache: murbhip_compute_acc / a leapfrog read-out evaluated the forces at the CURRENT positions
+    bool acc_current = false;        // acc_out holds them (a second evaluation would be bit-identical: skip it)
+    bool partials_current = false;   // ... and so do the partial-sum buffers of plan `acc_sig` (one shard, no exchange)
+    long acc_sig = 0;
     float lf_last_dt = 0.f;
     int force_exchange = 0;   // run the exchange even with one rank (self-test of the RCCL binding)
     int solo_shard = -1;      // >= 0: only this shard computes (timing aid: one rank's isolated timeline
@@ -361,7 +366,7 @@ int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
 inline float leapfrog_kick(const murbhip_ctx* c, float dt) { return c->lf_half ? 0.5f * (c->lf_last_dt + dt) : 0.5f * dt; }
 
 int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int update_state, const Plan* plan = nullptr,
-                      int scheme = -1)
+                      int scheme = -1, float* acc_out = nullptr)
 {
     MurbIntegrateArgs a{};
     a.scheme = scheme >= 0 ? scheme : c->integrator;
@@ -376,7 +381,7 @@ int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int updat
     a.rec_out = sh.rec[c->cur ^ 1];
     a.vel = sh.vel;
     a.accp = sh.accp;
-    a.acc_out = sh.acc_out;
+    a.acc_out = acc_out ? acc_out : sh.acc_out;
     a.i_first_slot = (int)((unsigned long)sh.rank * c->slice);
     a.count = (int)sh.count;
     a.nparts = nparts;
@@ -684,13 +689,24 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
     const Plan p = make_plan(c);
     c->last_parts = p.parts_local + p.parts_remote;
     c->plan_waves = p.symmetric ? p.waves : 4;
-    if (p.symmetric && (c->world > 1 || c->force_exchange)) return enqueue_iteration_sym_multi(c, p, dt, update_state);
+    const long sig = 1 + p.variant + 100L * p.split + 10000L * p.waves + 1000000L * p.parts_local;
+    // forces at the current positions are already there (compute_acc, or a leapfrog read-out, just ran): a state
+    // update only needs the integrate launch (one shard without exchange), an evaluation nothing at all
+    const bool have_acc = c->acc_current && !update_state;
+    const bool have_partials = c->partials_current && c->acc_sig == sig && c->world == 1 && !c->force_exchange;
+    c->acc_current = c->partials_current = false;
+    if (have_acc) { c->acc_current = true; c->partials_current = have_partials; return 0; }
+    if (p.symmetric && (c->world > 1 || c->force_exchange)) {
+        RC_TRY(enqueue_iteration_sym_multi(c, p, dt, update_state));
+        c->acc_current = !update_state;
+        return 0;
+    }
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
         if (is_idle(c, sh)) continue;   // timing aid: see "solo_shard"
         if (c->world == 1) {
             if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
-            RC_TRY(enqueue_force(c, sh, p, 0));
+            if (!have_partials) RC_TRY(enqueue_force(c, sh, p, 0));
         } else if (c->overlap) {
             RC_TRY(enqueue_force(c, sh, p, 0));   // own slice: written by our own integrate, already ordered
             if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
@@ -705,6 +721,10 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
     if (update_state) {
         if (c->world > 1 || c->force_exchange) RC_TRY(enqueue_exchange(c, c->cur ^ 1));
         c->cur ^= 1;
+    } else {
+        c->acc_current = true;
+        c->partials_current = c->world == 1 && !c->force_exchange && c->solo_shard < 0;
+        c->acc_sig = sig;
     }
     return 0;
 }
@@ -952,7 +972,7 @@ int murbhip_destroy(murbhip_ctx* c)
         if (sh.ev_gathered) hipEventDestroy(sh.ev_gathered);
         if (sh.compute) hipStreamDestroy(sh.compute);
         if (sh.comm) hipStreamDestroy(sh.comm);
-        hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out); hipFree(sh.sym_part);
+        hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out); hipFree(sh.phi_out); hipFree(sh.sym_part);
         hipFree(sh.sym_items); hipFree(sh.sym_ranges); hipFree(sh.sym_send); hipFree(sh.sym_recv);
         hipFree(sh.sym_tri); hipFree(sh.sym_tri_acc);
         if (sh.ev_rowsum) hipEventDestroy(sh.ev_rowsum);
@@ -988,6 +1008,7 @@ int murbhip_upload(murbhip_ctx* c, const float* qx, const float* qy, const float
     c->gather_pending = false;
     c->uploaded = true;
     c->lf_half = false;
+    c->acc_current = c->partials_current = false;
     return 0;
 }
 
@@ -1133,6 +1154,7 @@ int murbhip_integrate_host_acc(murbhip_ctx* c, const float* ax, const float* ay,
     }
     if (c->world > 1) RC_TRY(enqueue_exchange(c, c->cur ^ 1));
     c->cur ^= 1;
+    c->acc_current = c->partials_current = false;
     return 0;
 }
 
@@ -1151,13 +1173,22 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
     }
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
+        if (!sh.phi_out) {
+            HIP_TRY(hipMalloc((void**)&sh.phi_out, 3 * c->slice * sizeof(float)));
+            sh.bytes += 3 * c->slice * sizeof(float);
+        }
         if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
         RC_TRY(enqueue_force(c, sh, p, 0));
         if (c->world > 1) RC_TRY(enqueue_force(c, sh, p, 1));
-        RC_TRY(enqueue_integrate(c, sh, p.parts_local + p.parts_remote, 0.f, 0));
+        RC_TRY(enqueue_integrate(c, sh, p.parts_local + p.parts_remote, 0.f, 0, nullptr, -1, sh.phi_out));
     }
-    std::vector<float> phi(c->n), unused(c->n), vx(c->n), vy(c->n), vz(c->n);
-    RC_TRY(murbhip_download_acc(c, phi.data(), unused.data(), unused.data()));
+    c->partials_current = c->partials_current && make_plan(c).symmetric;   // the sweep reuses the one-sided partial rows
+    RC_TRY(murbhip_sync(c));
+    std::vector<float> phi(c->n), vx(c->n), vy(c->n), vz(c->n);
+    for (Shard& sh : c->shards) {
+        HIP_TRY(hipSetDevice(sh.device));
+        HIP_TRY(hipMemcpy(phi.data() + sh.first, sh.phi_out, sh.count * sizeof(float), hipMemcpyDeviceToHost));
+    }
     RC_TRY(murbhip_download_state(c, nullptr, nullptr, nullptr, vx.data(), vy.data(), vz.data()));
     // O(N) part on the host in fp64, with the reference's definitions
     // (SimulationNBodyCUDAPropertyTracking.cu:287-294: self term removed, both halved)
@@ -1199,6 +1230,7 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
 {
     if (!c || !key) return MURBHIP_E_INVALID;
     const std::string k(key);
+    if (k != "profile") c->acc_current = c->partials_current = false;   // a new plan may lay its buffers out differently
     if (k == "variant") { if (value < 0 || value > kNumVariants) return MURBHIP_E_INVALID; c->variant = (int)value; }
     else if (k == "jsplit") { if (value < 0 || value > kMaxParts / 2) return MURBHIP_E_INVALID; c->jsplit = (int)value; }
     else if (k == "xcd_order") c->xcd_order = value ? 1 : 0;

@@ -721,3 +721,30 @@ def test_file_scheme_end_to_end(gpu, O, tmp_path, monkeypatch):
     O.integrate(ref, a, dt)
     for k in ("qx", "qy", "qz", "vx", "vy", "vz"):
         assert np.array_equal(bits(moved[k]), bits(ref[k])), k
+
+
+@pytest.mark.parametrize("n", [4000, 20000])
+@pytest.mark.parametrize("integrator", [0, 1])
+def test_remembered_forces_change_nothing(gpu, O, n, integrator):
+    """murbhip_compute_acc() results are remembered (a repeated call, a leapfrog read-out or a directly following
+    step reuse them).  Every mix of calls must land on the bits of the plain sequence."""
+    s = O.init_bodies(n, "galaxy")
+    with gpu.Simulation(n, soft=SOFT) as plain, gpu.Simulation(n, soft=SOFT) as mixed:
+        for sim in (plain, mixed):
+            sim.set_option("integrator", integrator)
+            sim.upload(s)
+        plain.steps(DT, 4)
+        a_ref = None
+        for k in range(4):
+            mixed.compute_acc(); mixed.compute_acc()
+            acc = mixed.acc()
+            mixed.energy(); mixed.moments(); mixed.state()
+            again = mixed.acc()                          # the energy sweep must not disturb the accelerations
+            assert all(np.array_equal(bits(x), bits(y)) for x, y in zip(acc, again))
+            if k == 1:
+                mixed.set_option("jsplit", 2)            # a plan change in between drops the remembered forces
+                mixed.set_option("jsplit", 0)
+            mixed.step(DT)
+        a, b = plain.state(), mixed.state()
+        for k in a:
+            assert np.array_equal(bits(a[k]), bits(b[k])), k
