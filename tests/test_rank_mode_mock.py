@@ -61,7 +61,7 @@ def run_ranks(tmp_path, world, n, steps, variant, overlap=1, jsplit=0, integrato
     (4, 10003, 1, 0, 0),     # one-sided, ragged partition
     (4, 20000, 8, 0, 0),     # no overlap
     (4, 20000, 8, 1, 4),
-    (5, 12000, 8, 2, 1),     # overlap mode 2, odd world
+    (3, 12000, 8, 2, 1),     # overlap mode 2 (at most 4 ranks here: the GPU box allows 6 processes on the card, pytest is one)
 ])
 def test_ranks_match_single_gpu(gpu, O, tmp_path, world, n, variant, overlap, jsplit):
     steps = 3
