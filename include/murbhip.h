@@ -88,7 +88,8 @@ int murbhip_create(murbhip_ctx** out, unsigned long n, float soft, float g, int 
 /* One process driving `ndev` GPUs (bodies block-partitioned over them, positions exchanged every
  * step).  `devices` lists HIP device ordinals; the same ordinal may appear more than once (the
  * shards then share that GPU — used to exercise the sharded path on a one-GPU machine).
- * exchange: 0 = device-to-device copies issued by this library, 1 = RCCL all-gather. */
+ * exchange: 0 = device-to-device copies and peer reads issued by this library, 1 = RCCL (all-gather of
+ * positions, reduce-scatter of accelerations under the pair-symmetric schedule; ncclCommInitAll). */
 int murbhip_create_sharded(murbhip_ctx** out, unsigned long n, float soft, float g, int ndev, const int* devices,
                            int exchange);
 
