@@ -748,3 +748,23 @@ def test_remembered_forces_change_nothing(gpu, O, n, integrator):
         a, b = plain.state(), mixed.state()
         for k in a:
             assert np.array_equal(bits(a[k]), bits(b[k])), k
+
+
+def test_beyond_the_partial_plane_budget(gpu, O):
+    """4 000 003 bodies: the pair-symmetric kernel's partial-sum planes (N^2/1024 x 12 B = 187 GB) would take more
+    than half of the GPU's memory, so the automatic choice falls back to the one-sided kernel (no planes) —
+    checked against the fp64 sum on a subset, and through Newton's third law over all bodies."""
+    n = 4000003
+    s = O.init_bodies(n, "galaxy")
+    with gpu.Simulation(n, soft=SOFT) as sim:
+        assert int(sim.info("variant")) == 1
+        sim.upload(s)
+        sim.compute_acc()
+        sim.sync()
+        a = sim.acc()
+    idx = np.random.default_rng(3).choice(n, 512, replace=False)
+    assert O.rel_err(tuple(c[idx] for c in a), O.accel_f64_subset(s, idx, SOFT)).max() <= TOL_F64_MAX
+    m = s["m"].astype(np.float64)
+    tot = np.array([(m * c.astype(np.float64)).sum() for c in a])
+    scale = np.array([(m * np.abs(c.astype(np.float64))).sum() for c in a])
+    assert (np.abs(tot) / scale).max() <= 1e-6
