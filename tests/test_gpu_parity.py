@@ -768,3 +768,24 @@ def test_beyond_the_partial_plane_budget(gpu, O):
     tot = np.array([(m * c.astype(np.float64)).sum() for c in a])
     scale = np.array([(m * np.abs(c.astype(np.float64))).sum() for c in a])
     assert (np.abs(tot) / scale).max() <= 1e-6
+
+
+@pytest.mark.parametrize("shards,variant,overlap", [(4, 8, 1), (3, 8, 2), (4, 1, 1), (1, 8, 1)])
+def test_long_sharded_runs_are_bit_reproducible(gpu, O, shards, variant, overlap):
+    """2 000 steps of the multi-stream pipeline (force launches, row sums, peer reduce, integrate and the position
+    exchange on two or three streams per shard), twice: all sums are taken in a fixed order, so any difference
+    between the two runs would be a missing dependency between streams."""
+    n, steps = 12000, 2000
+    s = O.init_bodies(n, "galaxy")
+    out = []
+    for _ in range(2):
+        kw = {} if shards == 1 else {"devices": [0] * shards}
+        with gpu.Simulation(n, soft=SOFT, **kw) as sim:
+            sim.set_option("variant", variant)
+            sim.set_option("overlap", overlap)
+            sim.upload(s)
+            sim.steps(DT, steps)
+            out.append(sim.state())
+    for k in out[0]:
+        assert np.array_equal(bits(out[0][k]), bits(out[1][k])), k
+    assert all(np.isfinite(out[0][k]).all() for k in out[0])
