@@ -150,12 +150,13 @@ int murbhip_sync(murbhip_ctx* ctx);
 /* Mechanical energy of the current state: kinetic = sum 1/2 m v^2, potential = -1/2 sum_i sum_{j != i}
  * G m_i m_j / sqrt(r_ij^2 + soft^2) — the per-iteration metric of the reference's gpu+tracking
  * implementation (SimulationNBodyCUDAPropertyTracking.cu:217-304, summed there with cub).  One N^2
- * potential sweep on the device, the O(N) sum in fp64 on the host; waits for enqueued steps.  In rank
+ * potential sweep on the device, then the per-body terms summed in fp64 on the device (256-body block sums
+ * in a fixed order; the host adds the few hundred block rows); waits for enqueued steps.  In rank
  * mode the values cover the caller's own bodies only (sum them over ranks).  The accelerations of the
  * last evaluation (murbhip_download_acc) are left alone. */
 int murbhip_energy(murbhip_ctx* ctx, double* kinetic, double* potential);
 
-/* First moments of the current state, fp64 sums on the host over the caller's own bodies:
+/* First moments of the current state, fp64 sums (on the device, like murbhip_energy) over the caller's own bodies:
  *   out10 = { Px, Py, Pz,  Lx, Ly, Lz,  Mx, My, Mz,  M }
  * linear momentum sum m v, angular momentum sum m (q x v), mass-weighted position sum m q and total
  * mass (centre of mass = M{x,y,z} / M).  These fill the ang_momentum / density_center columns the

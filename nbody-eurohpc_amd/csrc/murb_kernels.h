@@ -482,4 +482,71 @@ __global__ __launch_bounds__(256) void murb_integrate_kernel(const MurbIntegrate
     a.vel[va] = VA; a.vel[va + MURB_TILE_PAIRS] = VB;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Tracked metrics: the O(N) sums of murbhip_energy / murbhip_moments on the device (the reference reduces
+// its per-body energy with cub::DeviceReduce::Sum, SimulationNBodyCUDAPropertyTracking.cu:330-356).
+// Per body, in fp64:  kinetic 1/2 m v^2 ; potential -1/2 m (phi - G m / soft) (self term of the sweep
+// removed, .cu:287-294) ; m v ; m q x v ; m q ; m.  One block = 256 consecutive slots of the rank's slice;
+// the 12 block sums are written in a fixed order (wave shuffle tree, then the 4 waves through LDS) and the
+// host adds the few hundred block rows in index order: bit-reproducible.
+#define MURB_METRIC_VALUES 12
+struct MurbMetricsArgs {
+    const float4* rec;      // positions + G*m, all slots
+    const float4* vel;      // local slice
+    const float* mass;      // local slice, as uploaded
+    const float* phi;       // potential sweep output (x plane), or null: potential = 0
+    const float* acc;       // ax | ay | az (acc_stride each), used for the closing half kick when half_dt != 0
+    double* out;            // [blocks][MURB_METRIC_VALUES]
+    int i_first_slot, count;
+    unsigned int acc_stride;
+    float half_dt;          // leapfrog read-out: v_n = v_{n-1/2} + a * half_dt (0: velocities are current)
+    double g_over_soft;     // G / soft
+};
+
+__global__ __launch_bounds__(256) void murb_metrics_kernel(const MurbMetricsArgs a)
+{
+#pragma clang fp contract(off)
+    __shared__ double red[3][MURB_METRIC_VALUES];
+    const int s = blockIdx.x * 256 + threadIdx.x;   // local slot
+    double v[MURB_METRIC_VALUES];
+#pragma unroll
+    for (int k = 0; k < MURB_METRIC_VALUES; ++k) v[k] = 0.0;
+    if (s < a.count) {
+        const unsigned long ra = murb_rec_a((unsigned long)((unsigned int)a.i_first_slot + s) >> 1);
+        const unsigned long va = murb_rec_a((unsigned long)(s >> 1));
+        const int h = s & 1;
+        const float4 A = a.rec[ra], B = a.rec[ra + MURB_TILE_PAIRS];
+        const float4 VA = a.vel[va], VB = a.vel[va + MURB_TILE_PAIRS];
+        float ux = h ? VA.y : VA.x, uy = h ? VA.w : VA.z, uz = h ? VB.y : VB.x;
+        if (a.half_dt != 0.f) {   // same rounding as the device kicks
+            ux = murb_add_rounded(ux, murb_kick(a.acc[s], a.half_dt));
+            uy = murb_add_rounded(uy, murb_kick(a.acc[a.acc_stride + s], a.half_dt));
+            uz = murb_add_rounded(uz, murb_kick(a.acc[2u * a.acc_stride + s], a.half_dt));
+        }
+        const double x = h ? A.y : A.x, y = h ? A.w : A.z, z = h ? B.y : B.x;
+        const double m = a.mass[s], wx = ux, wy = uy, wz = uz;
+        v[0] = 0.5 * m * (wx * wx + wy * wy + wz * wz);
+        v[1] = a.phi ? -0.5 * m * ((double)a.phi[s] - a.g_over_soft * m) : 0.0;
+        v[2] = m * wx; v[3] = m * wy; v[4] = m * wz;
+        v[5] = m * (y * wz - z * wy); v[6] = m * (z * wx - x * wz); v[7] = m * (x * wy - y * wx);
+        v[8] = m * x; v[9] = m * y; v[10] = m * z;
+        v[11] = m;
+    }
+#pragma unroll
+    for (int k = 0; k < MURB_METRIC_VALUES; ++k)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0 && wave > 0) {
+#pragma unroll
+        for (int k = 0; k < MURB_METRIC_VALUES; ++k) red[wave - 1][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < MURB_METRIC_VALUES; ++k)
+            a.out[(unsigned long)blockIdx.x * MURB_METRIC_VALUES + k] = ((v[k] + red[0][k]) + red[1][k]) + red[2][k];
+    }
+}
+
 #endif

@@ -62,6 +62,8 @@ struct Shard {
     float4* accp = nullptr;
     float* acc_out = nullptr;
     float* phi_out = nullptr;    // murbhip_energy's potential sweep (same shape as acc_out), allocated on first use
+    float* mass = nullptr;       // masses of the local slice as uploaded (metrics)
+    double* metrics = nullptr;   // block sums of murb_metrics_kernel
     float* sym_part = nullptr;   // pair-symmetric kernel: 3 planes of (slots/1024) rows, allocated on first use
     // multi-rank pair-symmetric schedule (half ring): item table, row ranges, reduce-scatter buffers
     int2* sym_items = nullptr;
@@ -95,7 +97,6 @@ struct murbhip_ctx {
     int exchange = 0;          // 0 peer copies, 1 RCCL
     bool rank_mode = false;    // one shard here, the others live in other processes
     std::vector<Shard> shards;
-    std::vector<float> host_mass;   // masses as uploaded (energy diagnostic)
     int cur = 0;               // record buffer holding the current positions
     bool uploaded = false;
     bool gather_pending = false;   // an exchange into rec[cur] is in flight on the comm streams
@@ -972,7 +973,7 @@ int murbhip_destroy(murbhip_ctx* c)
         if (sh.ev_gathered) hipEventDestroy(sh.ev_gathered);
         if (sh.compute) hipStreamDestroy(sh.compute);
         if (sh.comm) hipStreamDestroy(sh.comm);
-        hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out); hipFree(sh.phi_out); hipFree(sh.sym_part);
+        hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out); hipFree(sh.phi_out); hipFree(sh.mass); hipFree(sh.metrics); hipFree(sh.sym_part);
         hipFree(sh.sym_items); hipFree(sh.sym_ranges); hipFree(sh.sym_send); hipFree(sh.sym_recv);
         hipFree(sh.sym_tri); hipFree(sh.sym_tri_acc);
         if (sh.ev_rowsum) hipEventDestroy(sh.ev_rowsum);
@@ -1001,9 +1002,15 @@ int murbhip_upload(murbhip_ctx* c, const float* qx, const float* qy, const float
         HIP_TRY(hipMemcpy(sh.rec[0], rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(sh.rec[1], rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(sh.vel, vel.data(), vel.size() * sizeof(float4), hipMemcpyHostToDevice));
+        if (!sh.mass) {
+            HIP_TRY(hipMalloc((void**)&sh.mass, c->slice * sizeof(float)));
+            sh.bytes += c->slice * sizeof(float);
+        }
+        std::vector<float> mass(c->slice, 0.f);
+        std::copy(m + sh.first, m + sh.first + sh.count, mass.begin());
+        HIP_TRY(hipMemcpy(sh.mass, mass.data(), mass.size() * sizeof(float), hipMemcpyHostToDevice));
         sh.prof_used = 0;
     }
-    c->host_mass.assign(m, m + c->n);
     c->cur = 0;
     c->gather_pending = false;
     c->uploaded = true;
@@ -1158,12 +1165,62 @@ int murbhip_integrate_host_acc(murbhip_ctx* c, const float* ax, const float* ay,
     return 0;
 }
 
+namespace {
+// Leapfrog: the device holds v_{n-1/2}; anything that reports v_n needs a(q_n) (one force evaluation, remembered;
+// a collective in one-process-per-GPU mode).
+int ensure_acc_for_readout(murbhip_ctx* c)
+{
+    if (c->lf_half && !c->acc_current) RC_TRY(enqueue_iteration(c, 0.f, 0));
+    return 0;
+}
+
+// The O(N) sums of the tracked metrics over this process's bodies (murb_metrics_kernel + the block rows added
+// in index order on the host).  want_phi: the potential sweep has just been written to phi_out.
+int device_metrics(murbhip_ctx* c, bool want_phi, double (&sums)[MURB_METRIC_VALUES])
+{
+    const unsigned blocks = (unsigned)((c->slice + 255) / 256);
+    for (Shard& sh : c->shards) {
+        HIP_TRY(hipSetDevice(sh.device));
+        if (!sh.metrics) {
+            HIP_TRY(hipMalloc((void**)&sh.metrics, (size_t)blocks * MURB_METRIC_VALUES * sizeof(double)));
+            sh.bytes += (size_t)blocks * MURB_METRIC_VALUES * sizeof(double);
+        }
+        if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
+        MurbMetricsArgs a{};
+        a.rec = sh.rec[c->cur];
+        a.vel = sh.vel;
+        a.mass = sh.mass;
+        a.phi = want_phi ? sh.phi_out : nullptr;
+        a.acc = sh.acc_out;
+        a.out = sh.metrics;
+        a.i_first_slot = (int)((unsigned long)sh.rank * c->slice);
+        a.count = (int)sh.count;
+        a.acc_stride = (unsigned int)c->slice;
+        a.half_dt = c->lf_half ? 0.5f * c->lf_last_dt : 0.f;
+        a.g_over_soft = (double)c->g / std::sqrt((double)c->soft2);
+        hipLaunchKernelGGL(murb_metrics_kernel, dim3(blocks), dim3(256), 0, sh.compute, a);
+        RC_TRY(hip_rc(hipGetLastError()));
+    }
+    RC_TRY(murbhip_sync(c));
+    for (double& v : sums) v = 0.0;
+    std::vector<double> rows((size_t)blocks * MURB_METRIC_VALUES);
+    for (Shard& sh : c->shards) {
+        HIP_TRY(hipSetDevice(sh.device));
+        HIP_TRY(hipMemcpy(rows.data(), sh.metrics, rows.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (unsigned b = 0; b < blocks; ++b)
+            for (int k = 0; k < MURB_METRIC_VALUES; ++k) sums[k] += rows[(size_t)b * MURB_METRIC_VALUES + k];
+    }
+    return 0;
+}
+}  // namespace
+
 int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
 {
     if (!c || !kinetic || !potential) return MURBHIP_E_INVALID;
     if (!c->uploaded) return MURBHIP_E_STATE;
     // phi_i = sum_j GM_j / sqrt(r_ij^2 + soft^2) over ALL j (self term included) with the one-sided
     // sweep, written to the x plane of the acceleration output
+    RC_TRY(ensure_acc_for_readout(c));   // before the sweep: it reuses the one-sided partial rows
     Plan p{};
     p.variant = kPotentialKernel;
     {
@@ -1183,25 +1240,10 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
         RC_TRY(enqueue_integrate(c, sh, p.parts_local + p.parts_remote, 0.f, 0, nullptr, -1, sh.phi_out));
     }
     c->partials_current = c->partials_current && make_plan(c).symmetric;   // the sweep reuses the one-sided partial rows
-    RC_TRY(murbhip_sync(c));
-    std::vector<float> phi(c->n), vx(c->n), vy(c->n), vz(c->n);
-    for (Shard& sh : c->shards) {
-        HIP_TRY(hipSetDevice(sh.device));
-        HIP_TRY(hipMemcpy(phi.data() + sh.first, sh.phi_out, sh.count * sizeof(float), hipMemcpyDeviceToHost));
-    }
-    RC_TRY(murbhip_download_state(c, nullptr, nullptr, nullptr, vx.data(), vy.data(), vz.data()));
-    // O(N) part on the host in fp64, with the reference's definitions
-    // (SimulationNBodyCUDAPropertyTracking.cu:287-294: self term removed, both halved)
-    const double soft = std::sqrt((double)c->soft2), G = (double)c->g;
-    double ke = 0.0, pe = 0.0;
-    for (Shard& sh : c->shards)
-        for (unsigned long i = sh.first; i < sh.first + sh.count; ++i) {
-            const double m = c->host_mass[i];
-            ke += 0.5 * m * ((double)vx[i] * vx[i] + (double)vy[i] * vy[i] + (double)vz[i] * vz[i]);
-            pe -= 0.5 * m * ((double)phi[i] - G * m / soft);
-        }
-    *kinetic = ke;
-    *potential = pe;
+    double sums[MURB_METRIC_VALUES];
+    RC_TRY(device_metrics(c, true, sums));
+    *kinetic = sums[0];
+    *potential = sums[1];
     return 0;
 }
 
@@ -1209,20 +1251,10 @@ int murbhip_moments(murbhip_ctx* c, double* out10)
 {
     if (!c || !out10) return MURBHIP_E_INVALID;
     if (!c->uploaded) return MURBHIP_E_STATE;
-    std::vector<float> q[3], v[3];
-    for (int k = 0; k < 3; ++k) { q[k].resize(c->n); v[k].resize(c->n); }
-    RC_TRY(murbhip_download_state(c, q[0].data(), q[1].data(), q[2].data(), v[0].data(), v[1].data(), v[2].data()));
-    double s[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (Shard& sh : c->shards)
-        for (unsigned long i = sh.first; i < sh.first + sh.count; ++i) {
-            const double m = c->host_mass[i];
-            const double x = q[0][i], y = q[1][i], z = q[2][i], ux = v[0][i], uy = v[1][i], uz = v[2][i];
-            s[0] += m * ux; s[1] += m * uy; s[2] += m * uz;
-            s[3] += m * (y * uz - z * uy); s[4] += m * (z * ux - x * uz); s[5] += m * (x * uy - y * ux);
-            s[6] += m * x; s[7] += m * y; s[8] += m * z;
-            s[9] += m;
-        }
-    std::memcpy(out10, s, sizeof s);
+    RC_TRY(ensure_acc_for_readout(c));
+    double sums[MURB_METRIC_VALUES];
+    RC_TRY(device_metrics(c, false, sums));
+    std::memcpy(out10, sums + 2, 10 * sizeof(double));
     return 0;
 }
 
