@@ -113,6 +113,24 @@ __device__ __forceinline__ void murb_interact_sym(const murb_f2 xj, const murb_f
     ajz = __builtin_elementwise_fma(fj, dz, ajz);
 }
 
+// potential form: phi_i += G m_j / r, phi_j += G m_i / r (8 packed + 2 rsq per i x j-pair)
+__device__ __forceinline__ void murb_interact_sym_phi(const murb_f2 xj, const murb_f2 yj, const murb_f2 zj, const murb_f2 gj,
+                                                      const float xi, const float yi, const float zi, const float gi,
+                                                      const float soft2, murb_f2& phi_i, murb_f2& phi_j)
+{
+    const murb_f2 dx = xj - xi;
+    const murb_f2 dy = yj - yi;
+    const murb_f2 dz = zj - zi;
+    murb_f2 r2 = __builtin_elementwise_fma(dx, dx, (murb_f2)(soft2));
+    r2 = __builtin_elementwise_fma(dy, dy, r2);
+    r2 = __builtin_elementwise_fma(dz, dz, r2);
+    murb_f2 inv;
+    inv.x = __builtin_amdgcn_rsqf(r2.x);
+    inv.y = __builtin_amdgcn_rsqf(r2.y);
+    phi_i = __builtin_elementwise_fma(gj, inv, phi_i);
+    phi_j = __builtin_elementwise_fma(inv, (murb_f2)(gi), phi_j);
+}
+
 // grid.x = items; 64 * WAVES threads.  MINW = waves per SIMD the register allocator must allow.
 // WAVES = 4: one wave per SIMD and workgroup, four workgroups per CU.  WAVES = 8: two waves per SIMD and
 // workgroup, two workgroups per CU — an item takes half as long and a CU's last workgroup still has two
@@ -122,7 +140,9 @@ __device__ __forceinline__ void murb_interact_sym(const murb_f2 xj, const murb_f
 // constant address space, 4 per group) instead of 4 vector loads + 16 v_readfirstlane: 16 VALU issue slots
 // less per group of 576, +2.1 % at N=200k and +2.7 % at 30k, bit-identical results (tools/sload_lab.hip).
 // ILOAD = 0 keeps the vector-load form for that comparison.
-template <int MINW, int WAVES = 4, int ILOAD = 0>
+// PHI = 1: the same sweep for the potential (murbhip_energy): phi instead of the three acceleration components,
+// written to plane 0 only (the cells of planes 1 and 2 keep whatever they held; their row sums are not used).
+template <int MINW, int WAVES = 4, int ILOAD = 0, int PHI = 0>
 __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const MurbSymArgs a)
 {
     constexpr int R = MURB_SYM_R;
@@ -231,9 +251,13 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const 
             const float4 B = tileB[p * 64 + lane];
             const murb_f2 xj = {A.x, A.y}, yj = {A.z, A.w}, zj = {B.x, B.y}, gj = {B.z, B.w};
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                murb_interact_sym(xj, yj, zj, gj, xi[r], yi[r], zi[r], gi[r], soft2, aix[r], aiy[r], aiz[r], ajx[p],
-                                  ajy[p], ajz[p]);
+            for (int r = 0; r < R; ++r) {
+                if constexpr (PHI == 1)
+                    murb_interact_sym_phi(xj, yj, zj, gj, xi[r], yi[r], zi[r], gi[r], soft2, aix[r], ajx[p]);
+                else
+                    murb_interact_sym(xj, yj, zj, gj, xi[r], yi[r], zi[r], gi[r], soft2, aix[r], aiy[r], aiz[r], ajx[p],
+                                      ajy[p], ajz[p]);
+            }
             __builtin_amdgcn_sched_barrier(0);   // one step at a time: bounds the live temporaries
         }
 
@@ -283,8 +307,10 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const 
 #pragma unroll
             for (int p = 0; p < MURB_SYM_STEPS; ++p) {
                 px[p * 64 + lane] = ajx[p];
-                py[p * 64 + lane] = ajy[p];
-                pz[p * 64 + lane] = ajz[p];
+                if constexpr (PHI == 0) {
+                    py[p * 64 + lane] = ajy[p];
+                    pz[p * 64 + lane] = ajz[p];
+                }
             }
         }
     }

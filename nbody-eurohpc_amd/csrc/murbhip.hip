@@ -109,8 +109,6 @@ struct murbhip_ctx {
     bool lf_half = false;     // leapfrog: device velocities lag the positions by half a step of lf_last_dt
     // acceleration cache: murbhip_compute_acc / a leapfrog read-out evaluated the forces at the CURRENT positions
     bool acc_current = false;        // acc_out holds them (a second evaluation would be bit-identical: skip it)
-    bool partials_current = false;   // ... and so do the partial-sum buffers of plan `acc_sig` (one shard, no exchange)
-    long acc_sig = 0;
     float lf_last_dt = 0.f;
     int force_exchange = 0;   // run the exchange even with one rank (self-test of the RCCL binding)
     int solo_shard = -1;      // >= 0: only this shard computes (timing aid: one rank's isolated timeline
@@ -316,7 +314,7 @@ int prof_end(murbhip_ctx* c, Shard& sh)
 
 int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split);
 int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_planes = false,
-                       hipStream_t stream = nullptr);
+                       hipStream_t stream = nullptr, bool potential = false);
 
 // Force over the tiles of `which` (0 = own slice / everything when world == 1, 1 = all but own slice).
 int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
@@ -367,7 +365,7 @@ int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
 inline float leapfrog_kick(const murbhip_ctx* c, float dt) { return c->lf_half ? 0.5f * (c->lf_last_dt + dt) : 0.5f * dt; }
 
 int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int update_state, const Plan* plan = nullptr,
-                      int scheme = -1, float* acc_out = nullptr)
+                      int scheme = -1, float* acc_out = nullptr, bool acc_from_out = false)
 {
     MurbIntegrateArgs a{};
     a.scheme = scheme >= 0 ? scheme : c->integrator;
@@ -389,6 +387,7 @@ int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int updat
     a.acc_stride = (unsigned int)c->slice;
     a.dt = dt;
     a.update_state = update_state;
+    if (acc_from_out) a.acc_planes = sh.acc_out;   // remembered forces: nothing to sum
     if (plan && plan->symmetric) {   // one shard, triangular schedule: row sum of the partial planes + update in one launch
         hipLaunchKernelGGL(murb_sym_rowsum_integrate_kernel, dim3((unsigned)(c->slots / 64)), dim3(MURB_ROWSUM_THREADS), 0, sh.compute,
                            sh.sym_part, sh.sym_split * (int)(c->slots / MURB_SYM_BLOCK), (unsigned int)c->slots, sh.sym_split, a);
@@ -538,7 +537,8 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split)
     return 0;
 }
 
-int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_planes, hipStream_t stream)
+int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_planes, hipStream_t stream,
+                       bool potential)
 {
     if (count <= 0) return 0;
     if (!stream) stream = sh.compute;
@@ -559,9 +559,11 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
         sa.row_stride = (unsigned int)c->slots;
     }
     sa.soft2 = c->soft2;
-    const bool timed = stream == sh.compute;   // the profiling events live on the main compute stream
+    const bool timed = stream == sh.compute && !potential;   // the profiling events live on the main compute stream
     if (timed) RC_TRY(prof_begin(c, sh));
-    if (c->plan_waves == 8)
+    if (potential)   // murbhip_energy's sweep: phi into plane 0
+        hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1, 1>), dim3((unsigned)count), dim3(256), 0, stream, sa);
+    else if (c->plan_waves == 8)
         hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1>), dim3((unsigned)count), dim3(512), 0, stream, sa);
     else
         hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1>), dim3((unsigned)count), dim3(256), 0, stream, sa);
@@ -690,13 +692,12 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
     const Plan p = make_plan(c);
     c->last_parts = p.parts_local + p.parts_remote;
     c->plan_waves = p.symmetric ? p.waves : 4;
-    const long sig = 1 + p.variant + 100L * p.split + 10000L * p.waves + 1000000L * p.parts_local;
-    // forces at the current positions are already there (compute_acc, or a leapfrog read-out, just ran): a state
-    // update only needs the integrate launch (one shard without exchange), an evaluation nothing at all
-    const bool have_acc = c->acc_current && !update_state;
-    const bool have_partials = c->partials_current && c->acc_sig == sig && c->world == 1 && !c->force_exchange;
-    c->acc_current = c->partials_current = false;
-    if (have_acc) { c->acc_current = true; c->partials_current = have_partials; return 0; }
+    // forces at the current positions are already in acc_out (compute_acc, or a leapfrog read-out, just ran): an
+    // evaluation needs nothing at all, a state update (one shard, no exchange) only the integrate launch
+    const bool have_acc = c->acc_current;
+    c->acc_current = false;
+    if (have_acc && !update_state) { c->acc_current = true; return 0; }
+    const bool reuse = have_acc && c->world == 1 && !c->force_exchange && c->solo_shard < 0;
     if (p.symmetric && (c->world > 1 || c->force_exchange)) {
         RC_TRY(enqueue_iteration_sym_multi(c, p, dt, update_state));
         c->acc_current = !update_state;
@@ -707,7 +708,7 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
         if (is_idle(c, sh)) continue;   // timing aid: see "solo_shard"
         if (c->world == 1) {
             if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
-            if (!have_partials) RC_TRY(enqueue_force(c, sh, p, 0));
+            if (!reuse) RC_TRY(enqueue_force(c, sh, p, 0));
         } else if (c->overlap) {
             RC_TRY(enqueue_force(c, sh, p, 0));   // own slice: written by our own integrate, already ordered
             if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
@@ -717,15 +718,13 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
             RC_TRY(enqueue_force(c, sh, p, 0));
             RC_TRY(enqueue_force(c, sh, p, 1));
         }
-        RC_TRY(enqueue_integrate(c, sh, p.parts_local + p.parts_remote, dt, update_state, &p));
+        RC_TRY(enqueue_integrate(c, sh, p.parts_local + p.parts_remote, dt, update_state, reuse ? nullptr : &p, -1, nullptr, reuse));
     }
     if (update_state) {
         if (c->world > 1 || c->force_exchange) RC_TRY(enqueue_exchange(c, c->cur ^ 1));
         c->cur ^= 1;
     } else {
         c->acc_current = true;
-        c->partials_current = c->world == 1 && !c->force_exchange && c->solo_shard < 0;
-        c->acc_sig = sig;
     }
     return 0;
 }
@@ -1015,7 +1014,7 @@ int murbhip_upload(murbhip_ctx* c, const float* qx, const float* qy, const float
     c->gather_pending = false;
     c->uploaded = true;
     c->lf_half = false;
-    c->acc_current = c->partials_current = false;
+    c->acc_current = false;
     return 0;
 }
 
@@ -1161,7 +1160,7 @@ int murbhip_integrate_host_acc(murbhip_ctx* c, const float* ax, const float* ay,
     }
     if (c->world > 1) RC_TRY(enqueue_exchange(c, c->cur ^ 1));
     c->cur ^= 1;
-    c->acc_current = c->partials_current = false;
+    c->acc_current = false;
     return 0;
 }
 
@@ -1228,6 +1227,10 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
         p.parts_local = std::max(1, auto_parts(c, 1, c->slice, tiles_local));
         p.parts_remote = c->world > 1 ? std::max(1, std::min<int>(auto_parts(c, 1, c->slice, tiles_remote), kMaxParts / 2)) : 0;
     }
+    // one shard on the pair-symmetric plan: the sweep is pair-symmetric too (phi_i += G m_j / r, phi_j += G m_i / r:
+    // 8 packed + 2 rsq per 4 pair terms instead of 7 + 2 per 2), through the force kernel's partial planes
+    const Plan main_plan = make_plan(c);
+    const bool symmetric_sweep = main_plan.symmetric && c->world == 1 && !c->force_exchange;
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
         if (!sh.phi_out) {
@@ -1235,11 +1238,19 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
             sh.bytes += 3 * c->slice * sizeof(float);
         }
         if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
+        if (symmetric_sweep) {
+            RC_TRY(build_sym_schedule(c, sh, main_plan.split));
+            RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_total, false, nullptr, true));
+            hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slots / 64)), dim3(MURB_ROWSUM_THREADS), 0, sh.compute,
+                               sh.sym_part, sh.sym_split * (int)(c->slots / MURB_SYM_BLOCK), (unsigned int)c->slots,
+                               (const MurbSymRowRanges*)nullptr, sh.sym_split, sh.phi_out);
+            RC_TRY(hip_rc(hipGetLastError()));
+            continue;
+        }
         RC_TRY(enqueue_force(c, sh, p, 0));
         if (c->world > 1) RC_TRY(enqueue_force(c, sh, p, 1));
         RC_TRY(enqueue_integrate(c, sh, p.parts_local + p.parts_remote, 0.f, 0, nullptr, -1, sh.phi_out));
     }
-    c->partials_current = c->partials_current && make_plan(c).symmetric;   // the sweep reuses the one-sided partial rows
     double sums[MURB_METRIC_VALUES];
     RC_TRY(device_metrics(c, true, sums));
     *kinetic = sums[0];
@@ -1262,7 +1273,7 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
 {
     if (!c || !key) return MURBHIP_E_INVALID;
     const std::string k(key);
-    if (k != "profile") c->acc_current = c->partials_current = false;   // a new plan may lay its buffers out differently
+    if (k == "solo_shard" || k == "force_exchange") c->acc_current = false;   // what acc_out covers changes
     if (k == "variant") { if (value < 0 || value > kNumVariants) return MURBHIP_E_INVALID; c->variant = (int)value; }
     else if (k == "jsplit") { if (value < 0 || value > kMaxParts / 2) return MURBHIP_E_INVALID; c->jsplit = (int)value; }
     else if (k == "xcd_order") c->xcd_order = value ? 1 : 0;
