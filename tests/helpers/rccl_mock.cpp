@@ -25,11 +25,24 @@ struct Segment {
     int nranks;
     char data[1];
 };
+struct LocalGroup;   // one process driving several "devices" (ncclCommInitAll)
 struct Comm {
     Segment* seg = nullptr;
     int rank = 0, nranks = 1;
     std::string name;
+    LocalGroup* local = nullptr;
+    int device = 0;
 };
+struct PendingOp {
+    int kind;   // 0 all-gather, 1 reduce-scatter
+    const void* send; void* recv; size_t count; Comm* comm; hipStream_t stream;
+};
+struct LocalGroup {
+    int nranks = 0, alive = 0;
+    std::vector<PendingOp> pending;
+};
+int group_depth = 0;
+std::vector<LocalGroup*> touched;   // groups with pending work inside the current ncclGroupStart/End
 struct Id { char bytes[128]; };
 std::string segment_name(const Id& id)
 {
@@ -97,12 +110,30 @@ int ncclCommInitRank(void** out, int nranks, Id id, int rank)
     return kOk;
 }
 
-int ncclCommInitAll(void**, int, const int*) { return kInvalid; }   // one process, several devices: not mocked
+// one process, several "devices" (the same ordinal may repeat): the collectives are executed at ncclGroupEnd,
+// when every rank's call has been recorded
+int ncclCommInitAll(void** out, int ndev, const int* devices)
+{
+    if (!out || ndev < 1 || !devices) return kInvalid;
+    LocalGroup* g = new LocalGroup;
+    g->nranks = g->alive = ndev;
+    for (int r = 0; r < ndev; ++r) {
+        Comm* c = new Comm;
+        c->rank = r; c->nranks = ndev; c->local = g; c->device = devices[r];
+        out[r] = c;
+    }
+    return kOk;
+}
 
 int ncclCommDestroy(void* comm)
 {
     Comm* c = static_cast<Comm*>(comm);
     if (!c) return kOk;
+    if (c->local) {
+        if (--c->local->alive == 0) delete c->local;
+        delete c;
+        return kOk;
+    }
     pthread_barrier_wait(&c->seg->barrier);
     munmap(c->seg, sizeof(Segment) + kCapacity);
     if (c->rank == 0) shm_unlink(c->name.c_str());
@@ -115,6 +146,12 @@ int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* c
 {
     Comm* c = static_cast<Comm*>(comm);
     const size_t bytes = count * 4;
+    if (c && c->local) {
+        if (dtype != 7 || group_depth == 0) return kInvalid;
+        c->local->pending.push_back(PendingOp{0, send, recv, count, c, stream});
+        touched.push_back(c->local);
+        return kOk;
+    }
     if (!c || dtype != 7 || bytes * c->nranks > kCapacity) return kInvalid;
     if (hipStreamSynchronize(stream) != hipSuccess) return kSystem;
     if (hipMemcpy(c->seg->data + (size_t)c->rank * bytes, send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return kSystem;
@@ -128,6 +165,12 @@ int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* c
 int ncclReduceScatter(const void* send, void* recv, size_t recvcount, int dtype, int op, void* comm, hipStream_t stream)
 {
     Comm* c = static_cast<Comm*>(comm);
+    if (c && c->local) {
+        if (dtype != 7 || op != 0 || group_depth == 0) return kInvalid;
+        c->local->pending.push_back(PendingOp{1, send, recv, recvcount, c, stream});
+        touched.push_back(c->local);
+        return kOk;
+    }
     const size_t block = recvcount * 4, mine = block * c->nranks;
     if (!c || dtype != 7 || op != 0 || mine * c->nranks > kCapacity) return kInvalid;
     if (hipStreamSynchronize(stream) != hipSuccess) return kSystem;
@@ -143,8 +186,47 @@ int ncclReduceScatter(const void* send, void* recv, size_t recvcount, int dtype,
     return kOk;
 }
 
-int ncclGroupStart() { return kOk; }
-int ncclGroupEnd() { return kOk; }
+static int run_local(LocalGroup* g)
+{
+    if (g->pending.empty()) return kOk;
+    if ((int)g->pending.size() != g->nranks) return kInvalid;   // every rank must have made the same single call
+    const int kind = g->pending[0].kind;
+    const size_t count = g->pending[0].count, n = (size_t)g->nranks;
+    std::vector<std::vector<float>> host(n);
+    for (const PendingOp& op : g->pending) {
+        if (op.kind != kind || op.count != count) return kInvalid;
+        const size_t floats = kind == 0 ? count : count * n;
+        host[op.comm->rank].resize(floats);
+        if (hipSetDevice(op.comm->device) != hipSuccess || hipStreamSynchronize(op.stream) != hipSuccess ||
+            hipMemcpy(host[op.comm->rank].data(), op.send, floats * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return kSystem;
+    }
+    for (const PendingOp& op : g->pending) {
+        std::vector<float> out(kind == 0 ? count * n : count, 0.f);
+        if (kind == 0)
+            for (size_t r = 0; r < n; ++r) std::copy(host[r].begin(), host[r].end(), out.begin() + r * count);
+        else
+            for (size_t r = 0; r < n; ++r)
+                for (size_t k = 0; k < count; ++k) out[k] += host[r][(size_t)op.comm->rank * count + k];
+        if (hipSetDevice(op.comm->device) != hipSuccess ||
+            hipMemcpy(op.recv, out.data(), out.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+            return kSystem;
+    }
+    g->pending.clear();
+    return kOk;
+}
+
+int ncclGroupStart() { ++group_depth; return kOk; }
+int ncclGroupEnd()
+{
+    if (group_depth > 0 && --group_depth == 0) {
+        int rc = kOk;
+        for (LocalGroup* g : touched) { const int r = run_local(g); if (r != kOk) rc = r; }
+        touched.clear();
+        return rc;
+    }
+    return kOk;
+}
 const char* ncclGetErrorString(int code) { return code == kOk ? "no error" : code == kInvalid ? "mock: invalid argument" : "mock: system error"; }
 
 }  // extern "C"

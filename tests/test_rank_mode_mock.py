@@ -141,3 +141,16 @@ def test_bench_py_with_several_ranks(gpu, world, n):
     chk = d["rank_mode_check"]
     assert chk["positions_identical_on_all_ranks"] and chk["finite"] and chk["max_position_diff_rel"] < 1e-4, chk
     assert "cpu_baseline" not in d      # rank 0 at N = 1 only
+
+
+@pytest.mark.parametrize("shards,n,variant,overlap", [(2, 9000, 8, 1), (3, 9001, 8, 0), (4, 20000, 8, 1), (3, 9000, 1, 1)])
+def test_one_process_several_shards_over_rccl_calls(gpu, shards, n, variant, overlap):
+    """`--im hip+tile+multi` on a multi-GPU node = murbhip_create_sharded(..., exchange = RCCL): ncclCommInitAll and
+    one ncclGroupStart/End around the shards' all-gather (and reduce-scatter) calls.  With all shards on GPU 0 the
+    calls go to the stand-in library, which executes them at ncclGroupEnd."""
+    if not os.path.exists(MOCK):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "helpers")], check=True, timeout=600)
+    env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_sharded_rccl_worker.py"), str(shards), str(n), str(variant),
+                        str(overlap)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
