@@ -43,3 +43,11 @@ def O():
 
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def free_port():
+    """A TCP port that is free right now on 127.0.0.1 (torch.distributed.run rendezvous of the tests)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]

@@ -553,10 +553,10 @@ def test_bench_under_torchrun_one_rank(gpu):
     import json
     import subprocess
     import sys
-    from conftest import ROOT
+    from conftest import ROOT, free_port
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--bodies", "30000", "--steps", "20",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--bodies", "30000", "--steps", "20",
            "--warmup", "2", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]

@@ -13,7 +13,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 
 pytestmark = pytest.mark.gpu
 
@@ -129,7 +129,7 @@ def test_bench_py_with_several_ranks(gpu, world, n):
     env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK, MURB_BENCH_BACKEND="gloo", MURB_BENCH_SHARE_GPU="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-           "127.0.0.1", "--master-port", str(29560 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--bodies",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--bodies",
            str(n), "--steps", "10", "--warmup", "2"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
