@@ -188,6 +188,10 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  *                    device keeps v_{n-1/2}, murbhip_download_state applies the closing half kick (one
  *                    extra force evaluation; a collective in rank mode).  Cannot be changed between a
  *                    leapfrog step and the next murbhip_upload (MURBHIP_E_STATE)
+ *   "tri_first_pct"  "overlap" 1, pair-symmetric schedule: percentage (0..100, default 50) of the own-slice
+ *                    triangle that is launched before the rectangles, i.e. under the all-gather of positions;
+ *                    the rest runs under the reduce-scatter of accelerations.  A tuning knob for real
+ *                    interconnect latencies (bench.py picks it per run, untimed)
  *   "solo_shard"     r >= 0: in a sharded context only shard r launches force work (timing aid: the
  *                    isolated per-step timeline of one rank of W; results are meaningless).  -1 = off
  *   "force_exchange" 1: run the position exchange even with a single rank/shard (self-test of the

@@ -104,6 +104,8 @@ struct murbhip_ctx {
     // options
     int variant = 0, jsplit = 0, profile = 0, overlap = 1;
     int sym_waves = 0;        // pair-symmetric kernel: waves per workgroup, 0 = auto, 4 or 8
+    int tri_first_pct = 50;   // overlap 1: share of the own-slice triangle launched BEFORE the rectangles (under the
+                              // position gather); the rest runs under the reduce-scatter
     int xcd_order = 0;        // pair-symmetric kernel: 1 = item table interleaved into one run per XCD (measured worse)
     int integrator = 0;       // 0 the reference's update (Bodies.cpp:260-278), 1 kick-drift-kick leapfrog
     bool lf_half = false;     // leapfrog: device velocities lag the positions by half a step of lf_last_dt
@@ -592,7 +594,7 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
         HIP_TRY(hipSetDevice(sh.device));
         RC_TRY(build_sym_schedule(c, sh, p.split));
         if (is_idle(c, sh)) continue;   // "solo_shard" timing aid: idle shards enqueue nothing at all
-        const int own = sh.sym_items_own, t1 = c->overlap == 1 ? own / 2 : 0;
+        const int own = sh.sym_items_own, t1 = c->overlap == 1 ? (int)((long)own * c->tri_first_pct / 100) : 0;
         if (c->overlap == 2) {
             // the whole own-slice triangle on a second, lowest-priority compute stream: it runs alone while
             // the positions are still being gathered, then fills the gaps and the tail of the rectangles
@@ -649,7 +651,7 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
         HIP_TRY(hipSetDevice(sh.device));
         HIP_TRY(hipEventRecord(sh.ev_reduced, sh.comm));
         // meanwhile: the rest of the own-slice triangle and its row sum
-        const int own = sh.sym_items_own, t1 = c->overlap == 1 ? own / 2 : 0;
+        const int own = sh.sym_items_own, t1 = c->overlap == 1 ? (int)((long)own * c->tri_first_pct / 100) : 0;
         if (c->overlap == 2) {
             HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_tri, 0));
         } else {
@@ -1277,6 +1279,7 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     if (k == "variant") { if (value < 0 || value > kNumVariants) return MURBHIP_E_INVALID; c->variant = (int)value; }
     else if (k == "jsplit") { if (value < 0 || value > kMaxParts / 2) return MURBHIP_E_INVALID; c->jsplit = (int)value; }
     else if (k == "xcd_order") c->xcd_order = value ? 1 : 0;
+    else if (k == "tri_first_pct") { if (value < 0 || value > 100) return MURBHIP_E_INVALID; c->tri_first_pct = (int)value; }
     else if (k == "sym_waves") { if (value != 0 && value != 4 && value != 8) return MURBHIP_E_INVALID; c->sym_waves = (int)value; }
     else if (k == "overlap") { if (value < 0 || value > 2) return MURBHIP_E_INVALID; c->overlap = (int)value; }
     else if (k == "integrator") {
