@@ -10,9 +10,9 @@
  *
  * Conventions
  *   - every function returns 0 on success, a negative value on failure:
- *       -1 … -999     : -(hipError_t)
- *       -1000 … -1999 : -(1000 + ncclResult_t)
- *       -2000 …       : MURBHIP_E_* argument / state errors
+ *       -1 … -1999    : -(hipError_t)
+ *       -2000 … -2999 : MURBHIP_E_* argument / state errors
+ *       -3000 … -3999 : -(3000 + ncclResult_t)
  *     murbhip_error_string() turns any of them into text.  The C++ wrapper maps non-zero to the
  *     reference's print-to-stderr + exit(code) convention
  *     (reference src/murb/implem/SimulationNBodyCUDATileFullDevice.cu:10-17).
@@ -96,8 +96,10 @@ int murbhip_create_sharded(murbhip_ctx** out, unsigned long n, float soft, float
 /* One process per GPU (torchrun / mpirun style).  Rank 0 calls murbhip_unique_id() and ships the
  * 128 bytes to every rank out of band; every rank then calls murbhip_create_rank().  Takes the place
  * of the reference's lazy MPI_Init/Comm_rank/Comm_size (SimulationNBodyMultiNode.cpp:62-73).
+ * At most 64 ranks (MURBHIP_E_INVALID beyond: the per-slice tables of the half-ring schedule are fixed-size).
  * RCCL is bound at run time (librccl.so.1 by soname, so a host that already loaded RCCL shares it);
- * the environment variable MURBHIP_RCCL_LIBRARY names a specific library file to bind instead. */
+ * the environment variable MURBHIP_RCCL_LIBRARY names a specific library file to bind instead ("none": behave as
+ * on a machine without RCCL: MURBHIP_E_NO_RCCL). */
 int murbhip_unique_id(void* id_out /* MURBHIP_UNIQUE_ID_BYTES */);
 int murbhip_create_rank(murbhip_ctx** out, unsigned long n, float soft, float g, int device, int rank, int world,
                         const void* unique_id);

@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 
 #include <cstdlib>
+#include <string>
 #include <hip/hip_runtime.h>
 
 #include "../../include/murbhip.h"
@@ -36,7 +37,9 @@ Rccl& rccl()
     if (r.lib || r.ok) return r;
     // MURBHIP_RCCL_LIBRARY: path of the library to bind instead (a site build of RCCL; the tests' mock).
     // RTLD_LOCAL for it: its ncclXxx symbols must not shadow those of an RCCL the host already loaded.
+    // "none": behave as on a machine without RCCL (MURBHIP_E_NO_RCCL; callers fall back to peer copies).
     const char* override_path = std::getenv("MURBHIP_RCCL_LIBRARY");
+    if (override_path && std::string(override_path) == "none") return r;
     if (override_path && *override_path) r.lib = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* nm : names) {

@@ -36,7 +36,7 @@ namespace {
 
 // ------------------------------------------------------------------------------------ error codes
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
-inline int nccl_rc(int r) { return r == 0 ? 0 : -(1000 + r); }
+inline int nccl_rc(int r) { return r == 0 ? 0 : -(3000 + r); }   // disjoint from -(hipError_t), which reaches past 1000
 
 #define HIP_TRY(expr)                        \
     do {                                     \
@@ -734,7 +734,7 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
 int create_common(murbhip_ctx** out, unsigned long n, float soft, float g, int world, int nlocal, const int* devices,
                   const int* ranks, int exchange, bool rank_mode)
 {
-    if (!out || n == 0 || world < 1 || nlocal < 1 || !(soft == soft)) return MURBHIP_E_INVALID;
+    if (!out || n == 0 || world < 1 || world > MURB_SYM_MAX_RANKS || nlocal < 1 || !(soft == soft)) return MURBHIP_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MURBHIP_E_NO_DEVICE;
     for (int i = 0; i < nlocal; ++i)
@@ -847,13 +847,13 @@ const char* murbhip_error_string(int code)
     if (code == MURBHIP_E_NO_DEVICE) return "murbhip: no usable HIP device";
     if (code == MURBHIP_E_NO_RCCL) return "murbhip: librccl could not be loaded";
     if (code == MURBHIP_E_NOMEM) return "murbhip: host allocation failed";
-    if (code <= -1000 && code > -2000) {
+    if (code <= -3000 && code > -4000) {
         Rccl& r = rccl();
-        snprintf(buf, sizeof buf, "RCCL error %d: %s", -code - 1000,
-                 (r.ok && r.GetErrorString) ? r.GetErrorString(-code - 1000) : "?");
+        snprintf(buf, sizeof buf, "RCCL error %d: %s", -code - 3000,
+                 (r.ok && r.GetErrorString) ? r.GetErrorString(-code - 3000) : "?");
         return buf;
     }
-    if (code < 0 && code > -1000) {
+    if (code < 0 && code > -2000) {
         snprintf(buf, sizeof buf, "HIP error %d: %s", -code, hipGetErrorString((hipError_t)(-code)));
         return buf;
     }
@@ -946,6 +946,7 @@ int murbhip_create_rank(murbhip_ctx** out, unsigned long n, float soft, float g,
                         const void* unique_id)
 {
     if (world < 1 || rank < 0 || rank >= world || (unsigned long)world > n) return MURBHIP_E_INVALID;
+    if (world > MURB_SYM_MAX_RANKS) return MURBHIP_E_INVALID;   // fixed-size per-slice tables (MurbSymRowRanges, MurbPeerPtrs)
     if (world > 1 && !unique_id) return MURBHIP_E_INVALID;
     if ((world > 1 || unique_id) && !rccl().ok) return MURBHIP_E_NO_RCCL;
     RC_TRY(create_common(out, n, soft, g, world, 1, &device, &rank, 1, true));

@@ -1,6 +1,6 @@
 // See Bodies.hpp.  The arithmetic of the three initial-condition schemes and of the integrator has
 // to come out bit-identical to the reference's (same rand() sequence, same float/double mix), which
-// tests/test_host_mirror.py checks against tests/golden/ (vectors made with the compiled reference).
+// tests/test_abi_and_host.py (test_product_initial_conditions_*) checks against tests/golden/ (vectors made with the compiled reference).
 // This file is compiled with the reference's host flags (-O3 -ffast-math, no -march).
 #include "core/Bodies.hpp"
 

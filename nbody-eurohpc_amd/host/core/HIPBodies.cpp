@@ -27,9 +27,14 @@ template <typename T> void HIPBodies<T>::bindDevice(T soft, T G, const std::vect
     if (ctx) { murbhip_destroy(ctx); ctx = nullptr; }
     if (devices.size() <= 1)
         murbhipCheck(murbhip_create(&ctx, this->n, soft, G, devices.empty() ? 0 : devices[0]), "murbhip_create");
-    else
-        murbhipCheck(murbhip_create_sharded(&ctx, this->n, soft, G, (int)devices.size(), devices.data(), exchange),
-                     "murbhip_create_sharded");
+    else {
+        int rc = murbhip_create_sharded(&ctx, this->n, soft, G, (int)devices.size(), devices.data(), exchange);
+        if (rc == MURBHIP_E_NO_RCCL && exchange == 1) {   // the in-process peer-copy exchange needs no library
+            std::fprintf(stderr, "librccl could not be loaded: exchanging positions with peer copies instead\n");
+            rc = murbhip_create_sharded(&ctx, this->n, soft, G, (int)devices.size(), devices.data(), 0);
+        }
+        murbhipCheck(rc, "murbhip_create_sharded");
+    }
     const dataSoA_t<T> &d = this->dataSoA;
     murbhipCheck(murbhip_upload(ctx, d.qx.data(), d.qy.data(), d.qz.data(), d.vx.data(), d.vy.data(), d.vz.data(),
                                 d.m.data()), "murbhip_upload");
