@@ -74,6 +74,20 @@ unsigned long murbhip_slot_of_body(unsigned long n, int world, unsigned long i);
 int murbhip_schedule_items(unsigned long n, int world, int rank, int split, int* pairs, unsigned long capacity,
                            unsigned long* count, unsigned long* own_count);
 
+/* Host only: the same work list as the pair-symmetric kernel consumes it, with the layout of its partial sums —
+ * what murbhip_step builds for (n, world, rank) under the given plan (`split` i-side sub-blocks per block, `waves` 4 or 8
+ * per workgroup, `taper_pct` % of each launch cut into finer items, `tri_first_pct` % of the own-slice triangle in its
+ * first launch; exchange_mode != 0 or world > 1: the three-launch pipeline with separate rows for the own-slice
+ * triangle).  Per item 8 longs: first i slot, number of i bodies, j block, flags (bit 0 = diagonal), row set (0 main,
+ * 1 own-slice triangle), float offset of its i-side output, of its j-side output, launch (0, 1, 2).  Per row-table
+ * entry 7 longs: row set, destination slice chunk, block inside it, offset and count of its i rows, offset and count of
+ * its j rows (rows are 1024 slots).  NULL arrays query the counts.  Exists so that "every cell of every row has exactly
+ * one writer" and "every pair is evaluated once" can be checked without a GPU. */
+int murbhip_schedule_layout(unsigned long n, int world, int rank, int split, int waves, int taper_pct, int tri_first_pct,
+                            int exchange_mode, long* items, unsigned long item_capacity, unsigned long* item_count, long* rows,
+                            unsigned long row_capacity, unsigned long* row_count, unsigned long* floats_main,
+                            unsigned long* floats_tri);
+
 /* ------------------------------------------------------------------ life cycle */
 
 /* Number of visible HIP devices. */
@@ -175,6 +189,9 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  *                    the one-sided kernel (1) otherwise.  1-6: one-sided variants, 7: persistent schedule
  *   "jsplit"         one-sided variants: number of j-chunks a body's sum is split into; variant 7:
  *                    scheduling rounds; variant 8: i-side sub-blocks per item (1, 2, 4, 8, 16).  0 = auto
+ *   "taper"          variant 8: percentage (0..100) of each launch's work whose items are cut finer (the last
+ *                    taper % in halves, the last taper/2 % in quarters): a shorter drain phase at the end of a launch.
+ *                    -1 (default) = the plan's own choice
  *   "sym_waves"      variant 8: waves per workgroup, 4 or 8; 0 = auto (8, with `split` 8, on one GPU below
  *                    45 000 bodies: a short launch drains faster; 4 otherwise)
  *   "xcd_order"      variant 8: 0 (default) = j-major item order (round-robin dispatch then gives XCD x the i
@@ -194,6 +211,10 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  *                    triangle that is launched before the rectangles, i.e. under the all-gather of positions;
  *                    the rest runs under the reduce-scatter of accelerations.  A tuning knob for real
  *                    interconnect latencies (bench.py picks it per run, untimed)
+ *   "cu_reserve"     k >= 0 (default 0): the compute streams are re-created with a CU mask that leaves the k highest
+ *                    CUs (8 = one per XCD, 16 = two per XCD) to the exchange stream.  The force kernels otherwise fill
+ *                    every CU, and a collective's kernel (RCCL) has to wait for one of their workgroups to retire;
+ *                    costs k/256 of the force rate.  bench.py picks it per run for N > 1, like "tri_first_pct"
  *   "solo_shard"     r >= 0: in a sharded context only shard r launches force work (timing aid: the
  *                    isolated per-step timeline of one rank of W; results are meaningless).  -1 = off
  *   "force_exchange" 1: run the position exchange even with a single rank/shard (self-test of the
@@ -201,7 +222,7 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  */
 int murbhip_set_option(murbhip_ctx* ctx, const char* key, long value);
 
-/* Numeric facts.  Keys: "cu_count", "clock_mhz", "n", "slots", "world", "rank", "jsplit", "variant",
+/* Numeric facts.  Keys: "cu_count", "clock_mhz", "n", "slots", "world", "rank", "jsplit", "variant", "cu_reserve",
  * "workgroups", "force_launches", "force_ms_avg", "force_ms_total", "interactions_per_launch",
  * "device_bytes". */
 int murbhip_get_info(murbhip_ctx* ctx, const char* key, double* value);

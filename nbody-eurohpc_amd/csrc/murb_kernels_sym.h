@@ -18,13 +18,15 @@
 //     mirrors with a select): 39 instructions instead of 12 x 11, and written to partial row J;
 //   * at the end the four waves' j-side sums are combined through LDS in a fixed order and written
 //     to partial row I.  Diagonal items (I == J) evaluate the full square and only keep the i side.
-// Partial sums live in 3 planes of split*T rows.  Item (Isub, J) writes the i-side sums of its
-// sub-block's bodies to row split*J and the j-side sums of block J's bodies to row Isub: for a body of
-// block B the rows [0, split*B) hold j-side cells and the rows split*J (J >= B) i-side cells; every
-// cell has exactly one writer per launch, the remaining rows are never written (zeroed once at
-// allocation).  No atomics: the row sum is bit-reproducible.
-// `split` (1, 2, 4) cuts the i side of an item into sub-blocks: more, shorter items for small
-// problems and for the per-rank share of a multi-GPU run.
+// Partial sums: for every block B the launch owns two small matrices of 1024-slot rows, "i rows" (one per j block
+// that some item of block B's bodies walked against: the i-side sums) and "j rows" (one per item that had B as its j
+// block: the j-side sums), laid end to end in one buffer, once per component (x, y, z).  The host builds the layout
+// together with the item table (murbhip.hip: SymLayout) and hands every item the offsets of its two outputs, so the
+// kernel knows nothing about it; every cell has exactly one writer per launch, rows exist only where somebody writes
+// (a rank of a multi-GPU run holds just the rows of its own items), and a row sum in fp64 in a fixed order
+// (murb_sym_rowsum_*) turns them into accelerations.  No atomics: bit-reproducible.
+// The i range of an item is `ngroups` groups per wave (any multiple of 16 bodies with 4 waves): whole blocks for big
+// problems, fractions of a block for small ones and for the last items of a launch (shorter drain phase).
 #ifndef MURB_KERNELS_SYM_H_
 #define MURB_KERNELS_SYM_H_
 
@@ -35,17 +37,22 @@
 #define MURB_SYM_STEPS (MURB_SYM_PAIRS / 64)      /* 8 pair-vectors per lane          */
 #define MURB_SYM_R 4                              /* i bodies per group               */
 
+// One workgroup's work: the bodies [i_slot0, i_slot0 + ngroups * WAVES * R) against j block J.
+struct MurbSymItem {
+    int i_slot0;          // first slot (global, multiple of WAVES * R) of the i range
+    int ngroups;          // i groups of R bodies per WAVE
+    int J;                // j block (staged in LDS)
+    int flags;            // bit 0: diagonal item (the i range lies inside block J): full square, i side kept only
+    unsigned long ioff;   // float offset (component 0) where the i-side sums of slot i_slot0 go
+    unsigned long joff;   // float offset (component 0) where the j-side sums of block J's first slot go
+};
+
 struct MurbSymArgs {
-    const float4* rec;     // body records (murb_layout.h)
-    float* part;           // partial sums, 3 planes: part[(c * nrows + row) * row_stride + slot]
-    const int2* items;     // (Isub, J) per workgroup: the i side walks sub-block Isub (1024/split slots),
-                           // the j side is block J; block(Isub) = Isub / split <= J, equal = diagonal item
-    int item_first;        // first entry of `items` this launch evaluates
-    int split;             // sub-blocks per block on the i side: 1, 2 or 4 (finer items for small problems)
-    int plane_block0;      // block index that row 0 / slot 0 of `part` corresponds to (0 for planes that span
-                           // the whole record buffer; a rank's first block for its own-slice-only planes)
-    int nrows;             // rows per plane = split * (blocks in the record buffer)
-    unsigned int row_stride;   // floats per row (= slots of the record buffer)
+    const float4* rec;          // body records (murb_layout.h)
+    float* part;                // partial sums, 3 components of comp_stride floats each
+    unsigned long comp_stride;
+    const MurbSymItem* items;   // one per workgroup
+    int item_first;             // first entry of `items` this launch evaluates
     float soft2;
 };
 
@@ -154,15 +161,12 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    // item -> (Isub, J) from the host-built table
-    int I, J;
-    {
-        const int2 it = a.items[a.item_first + blockIdx.x];
-        I = it.x;
-        J = it.y;
-    }
-    I = __builtin_amdgcn_readfirstlane(I);
-    J = __builtin_amdgcn_readfirstlane(J);
+    // this workgroup's item from the host-built table (uniform address: scalar loads)
+    const MurbSymItem it = a.items[a.item_first + blockIdx.x];
+    const int J = __builtin_amdgcn_readfirstlane(it.J);
+    const int i_item_slot = __builtin_amdgcn_readfirstlane(it.i_slot0);
+    const int groups_per_wave = __builtin_amdgcn_readfirstlane(it.ngroups);
+    const bool diagonal = (__builtin_amdgcn_readfirstlane(it.flags) & 1) != 0;
     const float soft2 = a.soft2;
 #ifdef MURB_LAB_BEGIN     /* tools/sym_stamps.hip: per-workgroup time stamps (never defined in the product build) */
     MURB_LAB_BEGIN();
@@ -185,20 +189,14 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const 
 #pragma unroll
     for (int p = 0; p < MURB_SYM_STEPS; ++p) { ajx[p] = (murb_f2)(0.f); ajy[p] = (murb_f2)(0.f); ajz[p] = (murb_f2)(0.f); }
 
-    const int split = a.split;
-    const bool diagonal = (I / split) == J;
-    const int groups_per_wave = MURB_SYM_BLOCK / R / WAVES / split;  // WAVES = 4: 64, 32 or 16
-    const unsigned int i_block_slot = (unsigned int)I * (unsigned int)(MURB_SYM_BLOCK / split);
-    // the same item in the coordinates of the partial-sum planes
-    const int Ip = I - a.plane_block0 * split, Jp = J - a.plane_block0;
-    const unsigned int i_local_slot = (unsigned int)Ip * (unsigned int)(MURB_SYM_BLOCK / split);
+    const unsigned int i_block_slot = (unsigned int)i_item_slot;
     // where this lane's i-side total goes: value idx(lane) = 3 * body + component (see murb_reduce12)
     unsigned long out_off;
     {
         const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
         const int idx = b2 ? 8 + 2 * b4 + b5 : 4 * b3 + 2 * b4 + b5;
         const int r = idx / 3, c = idx - 3 * r;
-        out_off = ((unsigned long)c * a.nrows + (unsigned long)split * Jp) * a.row_stride + i_local_slot + r;
+        out_off = (unsigned long)c * a.comp_stride + it.ioff + r;
     }
 #pragma unroll 1
     for (int gk = 0; gk < groups_per_wave; ++gk) {
@@ -300,10 +298,9 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const 
             if (half > 1) __syncthreads();
         }
         if (wave == 0) {
-            const unsigned long base = (unsigned long)Jp * MURB_SYM_BLOCK;
-            murb_f2* px = reinterpret_cast<murb_f2*>(a.part + ((unsigned long)0 * a.nrows + Ip) * a.row_stride + base);
-            murb_f2* py = reinterpret_cast<murb_f2*>(a.part + ((unsigned long)1 * a.nrows + Ip) * a.row_stride + base);
-            murb_f2* pz = reinterpret_cast<murb_f2*>(a.part + ((unsigned long)2 * a.nrows + Ip) * a.row_stride + base);
+            murb_f2* px = reinterpret_cast<murb_f2*>(a.part + it.joff);
+            murb_f2* py = reinterpret_cast<murb_f2*>(a.part + a.comp_stride + it.joff);
+            murb_f2* pz = reinterpret_cast<murb_f2*>(a.part + 2ul * a.comp_stride + it.joff);
 #pragma unroll
             for (int p = 0; p < MURB_SYM_STEPS; ++p) {
                 px[p * 64 + lane] = ajx[p];
@@ -319,35 +316,40 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const 
 #endif
 }
 
-// Multi-rank schedule: which partial rows a rank has written for the bodies of each slice (up to
-// three ranges of block rows), and the row sum into the reduce-scatter send buffer, laid out as one
-// chunk per slice: send[slice][component][local slot].
+// ---- row sums -------------------------------------------------------------------------------------------
+// One entry per block a launch produced partial rows for: where its two matrices start (component 0), how many rows
+// each has, and where the block's totals go in the output (out[(out_slice * 3 + c) * out_slice_slots + out_block *
+// 1024 + slot]): the acceleration planes ax | ay | az of one GPU (out_slice = 0), or the reduce-scatter send buffer of
+// a multi-GPU rank, one chunk of [3][slice] per destination slice.
 #define MURB_SYM_MAX_RANKS 64
-struct MurbSymRowRanges {
-    int nslices, blocks_per_slice;
-    int first[MURB_SYM_MAX_RANKS][3], count[MURB_SYM_MAX_RANKS][3], stride[MURB_SYM_MAX_RANKS][3];
+struct MurbSymBlockRows {
+    unsigned long base_i, base_j;
+    int ni, nj;
+    int out_slice, out_block;
 };
 
-// Row sum of one slot: 64 * MURB_ROWSUM_GROUPS threads = 64 consecutive slots x 16 row groups.  Row group g
-// adds rows g, g+16, ... of each of the (up to three) row ranges in fp64; the partial sums are combined in
+// Row sum of one slot: 64 * MURB_ROWSUM_GROUPS threads = 64 consecutive slots x 16 row groups.  Row group g adds the
+// j rows g, g+16, ... and then the i rows g, g+16, ... of the slot's block in fp64; the partial sums are combined in
 // a fixed order through LDS.  Returns true on the threads of row group 0, which then hold the totals.
-// (16 groups, not 4: at N = 30 000 the planes have 120-480 rows of only 30 720 slots, and 4 groups left
-// the kernel latency-bound at 1.7 TB/s.)
+// (16 groups, not 4: at N = 30 000 a block has 30-270 rows of only 1024 slots, and 4 groups left the kernel
+// latency-bound at 1.7 TB/s.)
 #define MURB_ROWSUM_GROUPS 16
 #define MURB_ROWSUM_THREADS (64 * MURB_ROWSUM_GROUPS)
-__device__ __forceinline__ bool murb_sym_rowsum_slot(const float* part, int nrows, unsigned int row_stride,
-                                                     const int (&first)[3], const int (&count)[3], const int (&stride)[3],
-                                                     unsigned int s, int g, int lane,
+__device__ __forceinline__ bool murb_sym_rowsum_slot(const float* part, unsigned long comp_stride, const MurbSymBlockRows& br,
+                                                     unsigned int in_block, int g, int lane,
                                                      double (&red)[MURB_ROWSUM_GROUPS - 1][3][64], double (&total)[3])
 {
     double acc[3] = {0.0, 0.0, 0.0};
+    for (int idx = g; idx < br.nj; idx += MURB_ROWSUM_GROUPS) {
+        const unsigned long o = br.base_j + (unsigned long)idx * MURB_SYM_BLOCK + in_block;
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-        for (int idx = g; idx < count[k]; idx += MURB_ROWSUM_GROUPS) {
-            const unsigned long r = (unsigned long)(first[k] + idx * stride[k]);
+        for (int c = 0; c < 3; ++c) acc[c] += (double)part[(unsigned long)c * comp_stride + o];
+    }
+    for (int idx = g; idx < br.ni; idx += MURB_ROWSUM_GROUPS) {
+        const unsigned long o = br.base_i + (unsigned long)idx * MURB_SYM_BLOCK + in_block;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c] += (double)part[((unsigned long)c * nrows + r) * row_stride + s];
-        }
+        for (int c = 0; c < 3; ++c) acc[c] += (double)part[(unsigned long)c * comp_stride + o];
+    }
     if (g > 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) red[g - 1][c][lane] = acc[c];
@@ -364,59 +366,38 @@ __device__ __forceinline__ bool murb_sym_rowsum_slot(const float* part, int nrow
     return true;
 }
 
-// One rank owning everything (triangular schedule): the row ranges of a slot follow from its block B —
-// rows [0, split*B) hold j-side cells, rows split*J for J = B .. T-1 hold i-side cells.
-__device__ __forceinline__ void murb_sym_triangular_ranges(unsigned int s, int nrows, int split, int (&first)[3],
-                                                           int (&count)[3], int (&stride)[3])
-{
-    const int B = (int)(s / MURB_SYM_BLOCK), T = nrows / split;
-    first[0] = 0; count[0] = split * B; stride[0] = 1;
-    first[1] = split * B; count[1] = T - B; stride[1] = split;
-    first[2] = 0; count[2] = 0; stride[2] = 1;
-}
-
-// rr_ptr == null: triangular single-rank mode, else the multi-rank row ranges per slice.
-__global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_kernel(const float* part, int nrows,
-                                                                              unsigned int row_stride,
-                                                                              const MurbSymRowRanges* rr_ptr, int split,
-                                                                              float* send)
+// grid.x = 16 workgroups per table entry (64 slots each)
+__global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_kernel(const float* part, unsigned long comp_stride,
+                                                                              const MurbSymBlockRows* rows, float* out,
+                                                                              unsigned int out_slice_slots)
 {
     __shared__ double red[MURB_ROWSUM_GROUPS - 1][3][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const unsigned int s = blockIdx.x * 64 + lane;   // row_stride is a multiple of 1024: no partial block
-    int first[3], count[3], stride[3];
-    unsigned int sl = 0, local = s, slice_slots = row_stride;
-    if (rr_ptr) {
-        slice_slots = (unsigned int)rr_ptr->blocks_per_slice * MURB_SYM_BLOCK;
-        sl = s / slice_slots;
-        local = s - sl * slice_slots;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { first[k] = rr_ptr->first[sl][k]; count[k] = rr_ptr->count[sl][k]; stride[k] = rr_ptr->stride[sl][k]; }
-    } else {
-        murb_sym_triangular_ranges(s, nrows, split, first, count, stride);
-    }
+    const MurbSymBlockRows br = rows[blockIdx.x / (MURB_SYM_BLOCK / 64)];
+    const unsigned int in_block = (blockIdx.x % (MURB_SYM_BLOCK / 64)) * 64 + lane;
     double total[3];
-    if (!murb_sym_rowsum_slot(part, nrows, row_stride, first, count, stride, s, g, lane, red, total)) return;
+    if (!murb_sym_rowsum_slot(part, comp_stride, br, in_block, g, lane, red, total)) return;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) send[((unsigned long)sl * 3 + c) * slice_slots + local] = (float)total[c];
+    for (int c = 0; c < 3; ++c)
+        out[((unsigned long)br.out_slice * 3 + c) * out_slice_slots + (unsigned long)br.out_block * MURB_SYM_BLOCK + in_block] =
+            (float)total[c];
 }
 
-// Single GPU: the triangular row sum and the state update in ONE launch (a dependent launch costs ~6 us, 3 %
-// of an N = 30 000 step).  One thread per SLOT here (the stand-alone murb_integrate_kernel has one per
-// pair): the two lanes of a pair read the same records and write disjoint halves.  Same arithmetic, same
-// rounding as murb_sym_rowsum_kernel followed by murb_integrate_kernel.
-__global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_integrate_kernel(const float* part, int nrows,
-                                                                                        unsigned int row_stride, int split,
+// Single GPU: the row sum and the state update in ONE launch (a dependent launch costs ~6 us, 3 % of an
+// N = 30 000 step).  One thread per SLOT here (the stand-alone murb_integrate_kernel has one per pair): the two
+// lanes of a pair read the same records and write disjoint halves.  Same arithmetic, same rounding as
+// murb_sym_rowsum_kernel followed by murb_integrate_kernel.  The table has one entry per block, in block order.
+__global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_integrate_kernel(const float* part, unsigned long comp_stride,
+                                                                                        const MurbSymBlockRows* rows,
                                                                                         const MurbIntegrateArgs a)
 {
 #pragma clang fp contract(off)
     __shared__ double red[MURB_ROWSUM_GROUPS - 1][3][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const unsigned int s = blockIdx.x * 64 + lane;
-    int first[3], count[3], stride[3];
-    murb_sym_triangular_ranges(s, nrows, split, first, count, stride);
+    const MurbSymBlockRows br = rows[blockIdx.x / (MURB_SYM_BLOCK / 64)];
     double total[3];
-    if (!murb_sym_rowsum_slot(part, nrows, row_stride, first, count, stride, s, g, lane, red, total)) return;
+    if (!murb_sym_rowsum_slot(part, comp_stride, br, s % MURB_SYM_BLOCK, g, lane, red, total)) return;
     const float ax = (float)total[0], ay = (float)total[1], az = (float)total[2];
     a.acc_out[s] = ax;
     a.acc_out[a.acc_stride + s] = ay;

@@ -91,6 +91,44 @@ void sym_schedule_items(int world, int rank, int tb, int split, std::vector<int>
     xcd_interleave(flat, n_own, n_all);
 }
 
+// A piece of work for one workgroup of the pair-symmetric kernel: the i bodies [i_slot0, i_slot0 + len) against j
+// block J; `diag` = the i range lies inside block J (full square evaluated, i side kept).
+struct SymPiece {
+    int i_slot0, len, J;
+    bool diag;
+};
+
+// (i sub-block, j block) pairs -> pieces.  `taper_pct` > 0 cuts the i side of the LAST items of each launch finer:
+// the last taper_pct % of a launch's work in halves, the last taper_pct / 2 % in quarters (never below `min_len`
+// bodies).  The hardware deals workgroups in table order, so the drain phase of a launch — when the last workgroups
+// of each CU run alone at 61 % of the issue rate — then consists of short items.  `launch_ends` lists
+// the item indices (of `flat`) at which a launch ends (the last one = number of items).
+inline void sym_pieces(const std::vector<int>& flat, int split, int taper_pct, int min_len, const std::vector<size_t>& launch_ends,
+                       std::vector<SymPiece>& out, std::vector<size_t>& piece_launch_ends)
+{
+    const int len = MURB_SLICE_ALIGN / split;
+    out.clear();
+    piece_launch_ends.clear();
+    size_t first = 0;
+    for (size_t end : launch_ends) {
+        const double total = (double)(end - first);
+        for (size_t k = first; k < end; ++k) {
+            const int isub = flat[2 * k], J = flat[2 * k + 1];
+            const double before = (double)(k - first) / (total > 0 ? total : 1.0);
+            int div = 1;
+            if (taper_pct > 0) {
+                if (before >= 1.0 - taper_pct / 200.0) div = 4;
+                else if (before >= 1.0 - taper_pct / 100.0) div = 2;
+                while (div > 1 && len / div < min_len) div /= 2;
+            }
+            for (int q = 0; q < div; ++q)
+                out.push_back(SymPiece{isub * len + q * (len / div), len / div, J, isub / split == J});
+        }
+        piece_launch_ends.push_back(out.size());
+        first = end;
+    }
+}
+
 }  // namespace
 
 #endif

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -50,6 +51,14 @@ inline int nccl_rc(int r) { return r == 0 ? 0 : -(3000 + r); }   // disjoint fro
     } while (0)
 
 // ------------------------------------------------------------------------------------ context
+// Partial rows of one group of launches (murb_kernels_sym.h): the buffer, and per block the row table its row sum reads.
+struct SymSet {
+    float* part = nullptr;
+    size_t comp_stride = 0;           // floats per component
+    MurbSymBlockRows* rows = nullptr; // device copy of the table
+    int nblocks = 0;                  // entries
+};
+
 struct Shard {
     int device = 0;
     int rank = 0;
@@ -59,23 +68,25 @@ struct Shard {
     hipEvent_t ev_integrated = nullptr, ev_gathered = nullptr, ev_tri = nullptr;
     float4* rec[2] = {nullptr, nullptr};
     float4* vel = nullptr;
-    float4* accp = nullptr;
+    float4* accp = nullptr;      // one-sided kernels: partial-sum rows, allocated on first use (ensure_accp)
     float* acc_out = nullptr;
     float* phi_out = nullptr;    // murbhip_energy's potential sweep (same shape as acc_out), allocated on first use
     float* mass = nullptr;       // masses of the local slice as uploaded (metrics)
     double* metrics = nullptr;   // block sums of murb_metrics_kernel
-    float* sym_part = nullptr;   // pair-symmetric kernel: 3 planes of (slots/1024) rows, allocated on first use
-    // multi-rank pair-symmetric schedule (half ring): item table, row ranges, reduce-scatter buffers
-    int2* sym_items = nullptr;
+    // pair-symmetric kernel: item table and partial-row layouts (built by build_sym_schedule for one plan)
+    MurbSymItem* sym_items = nullptr;
     int sym_items_own = 0, sym_items_total = 0;   // [0, own) = own-slice triangle, the rest need the gathered positions
-    int sym_split = 0;                            // i-side sub-blocks per block the table was built for
+    int sym_split = 0, sym_waves = 0, sym_taper = -1;   // what the table was built for
     int sym_xcd_order = -1;                       // ... and the item order ("xcd_order")
+    int sym_tri_first = -1, sym_overlap = -1;     // ... and the launch boundaries inside the own-slice triangle ("tri_first_pct", "overlap")
+    int sym_t1 = 0;                               // items of the triangle's first launch (exchange pipeline, overlap 1)
     bool sym_exchange_mode = false;               // ... and whether it was built for the exchange pipeline
-    MurbSymRowRanges* sym_ranges = nullptr;
+    SymSet sym_main;             // one GPU: every item; exchange pipeline: the rectangles (-> reduce-scatter send chunks)
+    SymSet sym_tri;              // exchange pipeline: the own-slice triangle (never enters the reduce-scatter)
     float* sym_send = nullptr;   // [world][3][slice]
     float* sym_recv = nullptr;   // [3][slice]
-    float* sym_tri = nullptr;    // partial planes of the own-slice triangle only: 3 x (split*tb) rows x slice
-    float* sym_tri_acc = nullptr;// their row sums [3][slice]
+    float* sym_tri_acc = nullptr;// row sums of sym_tri [3][slice]
+    size_t sym_bytes = 0;        // device bytes of all of the above
     hipEvent_t ev_rowsum = nullptr, ev_reduced = nullptr;
     rccl_comm_t comm_rccl = nullptr;
     std::vector<hipEvent_t> prof;   // start/stop pairs around force launches
@@ -113,6 +124,8 @@ struct murbhip_ctx {
     bool acc_current = false;        // acc_out holds them (a second evaluation would be bit-identical: skip it)
     float lf_last_dt = 0.f;
     int force_exchange = 0;   // run the exchange even with one rank (self-test of the RCCL binding)
+    int taper = -1;           // pair-symmetric kernel: % of each launch cut into finer items (-1 = the plan's default)
+    int cu_reserve = 0;       // CUs masked out of the compute streams (left free for the collectives' kernels)
     int solo_shard = -1;      // >= 0: only this shard computes (timing aid: one rank's isolated timeline
                               // when W shards share one GPU; results are then meaningless)
     // facts
@@ -131,8 +144,9 @@ struct Plan {
     int parts_local, parts_remote;   // 2-D grid variants: j chunks of the own-slice launch and of the rest
     bool persistent;                 // balanced persistent schedule (murb_force_persistent)
     bool symmetric;                  // pair-symmetric kernel (murb_force_sym_kernel)
-    int split;                       // its i-side sub-blocks per block (1, 2, 4)
+    int split;                       // its i-side sub-blocks per block (1, 2, 4, 8, 16)
     int waves;                       // ... and its waves per workgroup (4 or 8)
+    int taper;                       // ... and the share (%) of each launch whose items are cut finer ("taper")
     MurbSchedule sched[2];           // [0] own slice (or everything), [1] the rest
 };
 
@@ -236,21 +250,27 @@ long sym_items_per_rank(const murbhip_ctx* c)
     return tb * (tb + 1) / 2 + ((w - 1) / 2) * tb * tb + (w > 1 && w % 2 == 0 ? tb * ((tb + 1) / 2) : 0);
 }
 
-// Bytes of the partial-sum planes of the pair-symmetric kernel (per rank).
+// Bytes of the partial rows of the pair-symmetric kernel on one rank for uniform items of 1024/split bodies
+// (12 B per row slot: three components).  One GPU: block b has split*b j rows and T-b i rows.  A rank of W: its
+// triangle (tb blocks) plus the rectangles against floor(W/2) slices: tb i rows per own block and split*tb j rows per
+// far block at most.
 size_t sym_plane_bytes(const murbhip_ctx* c, int split)
 {
-    return (size_t)3 * split * (c->slots / MURB_SYM_BLOCK) * c->slots * sizeof(float);
+    const size_t tb = c->slice / MURB_SYM_BLOCK, w = (size_t)c->world, far = w / 2;
+    size_t rows = tb * tb + (size_t)(split - 1) * tb * (tb - 1) / 2;
+    if (w > 1) rows += tb * far * tb + far * tb * (size_t)split * tb;
+    return rows * MURB_SYM_BLOCK * 3 * sizeof(float);
 }
 
 Plan make_plan(const murbhip_ctx* c)
 {
     Plan p{};
-    // variant 0 = auto: pair-symmetric when a GPU gets enough block pairs and its partial-sum planes fit
-    // comfortably (they grow as N^2/1024: 0.5 GB at 200k, 12 GB at 1M), else one-sided
-    const bool planes_fit = c->device_mem == 0 || sym_plane_bytes(c, 1) < c->device_mem / 2;
+    // variant 0 = auto: pair-symmetric when a GPU gets enough block pairs and its partial rows fit comfortably
+    // (they grow as N^2/1024 on one GPU: 0.5 GB at 200k, 12 GB at 1M; a rank of W holds ~1/W of that), else one-sided
+    const auto fits = [&](int split) { return c->device_mem == 0 || sym_plane_bytes(c, split) < c->device_mem / 2; };
     if (c->variant >= 1 && c->variant <= kNumVariants) p.variant = c->variant;
-    else if (c->world == 1) p.variant = (c->n >= kSymmetricMinBodies && planes_fit) ? kSymmetricVariant : kOneSidedVariant;
-    else p.variant = (sym_items_per_rank(c) >= 400 && planes_fit) ? kSymmetricVariant : kOneSidedVariant;
+    else if (c->world == 1) p.variant = (c->n >= kSymmetricMinBodies && fits(1)) ? kSymmetricVariant : kOneSidedVariant;
+    else p.variant = (sym_items_per_rank(c) >= 400 && fits(1)) ? kSymmetricVariant : kOneSidedVariant;
     p.symmetric = p.variant == kSymmetricVariant;
     if (p.symmetric) {
         // finer items (i side cut in 2 or 4) until a GPU has ~8 scheduling rounds of them; ~16 in the
@@ -265,6 +285,8 @@ Plan make_plan(const murbhip_ctx* c)
         // (tools/waves_lab.hip: +4 % at N=30k with split 8, nothing from 60k up): used for one GPU below 45k
         p.waves = (c->sym_waves == 4 || c->sym_waves == 8) ? c->sym_waves : ((c->world == 1 && c->n < 45000) ? 8 : 4);
         if (c->jsplit == 0 && c->sym_waves == 0 && p.waves == 8) p.split = 8;
+        while (p.split > 1 && !fits(p.split)) p.split /= 2;   // the rows of the split actually used must fit, too
+        p.taper = c->taper >= 0 ? c->taper : 0;
         p.persistent = false;
         p.parts_local = p.parts_remote = 0;
         return p;
@@ -314,7 +336,8 @@ int prof_end(murbhip_ctx* c, Shard& sh)
     return rc;
 }
 
-int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split);
+int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p);
+int ensure_accp(murbhip_ctx* c, Shard& sh);
 int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_planes = false,
                        hipStream_t stream = nullptr, bool potential = false);
 
@@ -322,6 +345,7 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
 int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
 {
     MurbForceArgs a{};
+    if (!p.symmetric) RC_TRY(ensure_accp(c, sh));
     a.rec = sh.rec[c->cur];
     a.accp = sh.accp;
     a.i_first_slot = (int)((unsigned long)sh.rank * c->slice);
@@ -341,7 +365,7 @@ int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
     const int i_slots = (int)sh.count;   // the grid rounds up to whole i groups; the extra slots hold mass 0
     if (p.symmetric) {   // one shard, no exchange: the whole triangle in one launch
         if (which != 0) return 0;
-        RC_TRY(build_sym_schedule(c, sh, p.split));
+        RC_TRY(build_sym_schedule(c, sh, p));
         RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_total));   // its row sum is fused into the integrate launch
         c->interactions_per_launch = (double)c->n * (double)c->n;
         return 0;
@@ -392,9 +416,10 @@ int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int updat
     if (acc_from_out) a.acc_planes = sh.acc_out;   // remembered forces: nothing to sum
     if (plan && plan->symmetric) {   // one shard, triangular schedule: row sum of the partial planes + update in one launch
         hipLaunchKernelGGL(murb_sym_rowsum_integrate_kernel, dim3((unsigned)(c->slots / 64)), dim3(MURB_ROWSUM_THREADS), 0, sh.compute,
-                           sh.sym_part, sh.sym_split * (int)(c->slots / MURB_SYM_BLOCK), (unsigned int)c->slots, sh.sym_split, a);
+                           sh.sym_main.part, sh.sym_main.comp_stride, sh.sym_main.rows, a);
         return hip_rc(hipGetLastError());
     }
+    if (!acc_from_out) RC_TRY(ensure_accp(c, sh));
     const unsigned pairs = (unsigned)(c->slice / 2);
     hipLaunchKernelGGL(murb_integrate_kernel, dim3((pairs + 255) / 256), dim3(256), 0, sh.compute, a);
     return hip_rc(hipGetLastError());
@@ -455,6 +480,126 @@ int enqueue_exchange(murbhip_ctx* c, int buf)
     return 0;
 }
 
+// The one-sided kernels' partial-sum rows: kMaxParts rows of float4 per local slot, zeroed once (rows a launch does
+// not write must read as 0).  Not needed by the pair-symmetric plan, so only allocated when a one-sided launch, the
+// one-sided potential sweep or murbhip_integrate_host_acc asks for it.
+int ensure_accp(murbhip_ctx* c, Shard& sh)
+{
+    if (sh.accp) return 0;
+    const size_t bytes = (size_t)kMaxParts * c->slice * sizeof(float4);
+    HIP_TRY(hipMalloc((void**)&sh.accp, bytes));
+    HIP_TRY(hipMemsetAsync(sh.accp, 0, bytes, sh.compute));
+    sh.bytes += bytes;
+    return 0;
+}
+
+void free_sym_set(SymSet& st)
+{
+    hipFree(st.part); hipFree(st.rows);
+    st = SymSet{};
+}
+
+// Lay out the partial rows of pieces [first, end): per block touched, an "i rows" matrix (one 1024-slot row per j block
+// its bodies were walked against) and a "j rows" matrix (one row per piece that had it as j block), end to end.  Fills
+// the pieces' output offsets into `items` and returns the per-block table; `out_of(block)` says where a block's row
+// sums go (slice chunk, block inside it).
+template <class OutOf>
+size_t layout_sym_set(const std::vector<SymPiece>& pieces, size_t first, size_t end, int waves, std::vector<MurbSymItem>& items,
+                      std::vector<MurbSymBlockRows>& table, OutOf out_of)
+{
+    std::map<int, int> index;                       // global block -> table entry, ascending block order
+    for (size_t k = first; k < end; ++k) { index[pieces[k].i_slot0 / MURB_SYM_BLOCK] = 0; if (!pieces[k].diag) index[pieces[k].J] = 0; }
+    table.assign(index.size(), MurbSymBlockRows{});
+    { int e = 0; for (auto& kv : index) { kv.second = e; const auto o = out_of(kv.first); table[e].out_slice = o.first; table[e].out_block = o.second; ++e; } }
+    std::vector<std::map<int, int>> irow(index.size());   // per block: j block -> i row
+    std::vector<int> item_irow(end - first), item_jrow(end - first);
+    for (size_t k = first; k < end; ++k) {
+        const SymPiece& pc = pieces[k];
+        const int bi = index[pc.i_slot0 / MURB_SYM_BLOCK];
+        auto f = irow[bi].find(pc.J);
+        if (f == irow[bi].end()) f = irow[bi].emplace(pc.J, table[bi].ni++).first;
+        item_irow[k - first] = f->second;
+        item_jrow[k - first] = pc.diag ? -1 : table[index[pc.J]].nj++;
+    }
+    size_t floats = 0;
+    for (MurbSymBlockRows& br : table) {
+        br.base_j = floats; floats += (size_t)br.nj * MURB_SYM_BLOCK;
+        br.base_i = floats; floats += (size_t)br.ni * MURB_SYM_BLOCK;
+    }
+    for (size_t k = first; k < end; ++k) {
+        const SymPiece& pc = pieces[k];
+        MurbSymItem& it = items[k];
+        it.i_slot0 = pc.i_slot0;
+        it.ngroups = pc.len / (waves * MURB_SYM_R);
+        it.J = pc.J;
+        it.flags = pc.diag ? 1 : 0;
+        const MurbSymBlockRows& bi = table[index[pc.i_slot0 / MURB_SYM_BLOCK]];
+        it.ioff = bi.base_i + (size_t)item_irow[k - first] * MURB_SYM_BLOCK + (size_t)(pc.i_slot0 % MURB_SYM_BLOCK);
+        it.joff = pc.diag ? 0 : table[index[pc.J]].base_j + (size_t)item_jrow[k - first] * MURB_SYM_BLOCK;
+    }
+    return floats;
+}
+
+int upload_sym_set(Shard& sh, SymSet& st, const std::vector<MurbSymBlockRows>& table, size_t floats)
+{
+    st.comp_stride = floats;
+    st.nblocks = (int)table.size();
+    if (floats == 0) return 0;
+    const size_t bytes = 3 * floats * sizeof(float);
+    HIP_TRY(hipMalloc((void**)&st.part, bytes));
+    HIP_TRY(hipMemsetAsync(st.part, 0, bytes, sh.compute));   // every cell has a writer; zero anyway (on OUR stream: non-blocking w.r.t. stream 0)
+    HIP_TRY(hipMalloc((void**)&st.rows, table.size() * sizeof(MurbSymBlockRows)));
+    HIP_TRY(hipMemcpy(st.rows, table.data(), table.size() * sizeof(MurbSymBlockRows), hipMemcpyHostToDevice));
+    sh.sym_bytes += bytes + table.size() * sizeof(MurbSymBlockRows);
+    return 0;
+}
+
+// Everything the pair-symmetric launches of one rank need, computed on the host without touching a device (unit-tested
+// on the CPU through murbhip_schedule_layout): the item table in launch order ([0, own) = own-slice triangle, its first
+// t1 items forming the launch that runs under the position gather), and the partial-row layout of the two sets.
+struct SymHostLayout {
+    std::vector<MurbSymItem> items;
+    int own = 0, t1 = 0;
+    std::vector<MurbSymBlockRows> table_main, table_tri;
+    size_t floats_main = 0, floats_tri = 0;
+};
+
+void plan_sym_layout(int W, int r, int tb, int split, int waves, int taper, bool exchange_mode, int overlap, int tri_first_pct,
+                     bool xcd_order, SymHostLayout& L)
+{
+    std::vector<int> flat;
+    int own = 0;
+    sym_schedule_items(W, r, tb, split, flat, &own, xcd_order);
+    // the launches of a step: one GPU = everything; exchange pipeline = triangle part 1, part 2, rectangles
+    const size_t n_all = flat.size() / 2;
+    const size_t t1 = (exchange_mode && overlap == 1) ? (size_t)((long)own * tri_first_pct / 100) : 0;
+    std::vector<size_t> launch_ends;
+    if (exchange_mode) {
+        if (t1 > 0) launch_ends.push_back(t1);
+        if ((size_t)own > t1) launch_ends.push_back((size_t)own);
+        if (n_all > (size_t)own) launch_ends.push_back(n_all);
+    } else {
+        launch_ends.push_back(n_all);
+    }
+    std::vector<SymPiece> pieces;
+    std::vector<size_t> piece_ends;
+    sym_pieces(flat, split, taper, 16 * waves, launch_ends, pieces, piece_ends);
+    size_t own_pieces = 0;   // pieces of the own-slice triangle = the leading ones whose j block is one of ours
+    for (const SymPiece& pc : pieces) { if (pc.J / tb != r) break; ++own_pieces; }
+    L.items.assign(pieces.size(), MurbSymItem{});
+    L.table_main.clear(); L.table_tri.clear();
+    L.floats_main = L.floats_tri = 0;
+    if (exchange_mode) {
+        L.floats_tri = layout_sym_set(pieces, 0, own_pieces, waves, L.items, L.table_tri, [&](int b) { return std::make_pair(0, b - r * tb); });
+        L.floats_main = layout_sym_set(pieces, own_pieces, pieces.size(), waves, L.items, L.table_main,
+                                       [&](int b) { return std::make_pair(b / tb, b % tb); });
+    } else {
+        L.floats_main = layout_sym_set(pieces, 0, pieces.size(), waves, L.items, L.table_main, [&](int b) { return std::make_pair(0, b); });
+    }
+    L.own = (int)own_pieces;
+    L.t1 = t1 > 0 ? (int)piece_ends[0] : 0;
+}
+
 // ---- pair-symmetric schedule over several ranks ("half ring") --------------------------------------
 // Rank r evaluates, once each, the block pairs of (own slice x own slice) and of (own slice x slice
 // r+d) for d = 1 .. floor(W/2); for even W the pair of slices half a ring apart is shared: the lower
@@ -462,80 +607,60 @@ int enqueue_exchange(murbhip_ctx* c, int buf)
 // unordered body pair is evaluated by exactly one rank.  A rank's partial sums for ALL slices it
 // touched are then row-summed into one chunk per slice and combined with ONE reduce-scatter (each
 // rank receives the complete accelerations of its own bodies); positions travel as before.
-int build_sym_schedule(murbhip_ctx* c, Shard& sh, int split)
+int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
 {
     const bool exchange_mode = c->world > 1 || c->force_exchange;
-    if (sh.sym_items && sh.sym_split == split && sh.sym_exchange_mode == exchange_mode && sh.sym_xcd_order == c->xcd_order) return 0;
-    if (sh.sym_items) {   // option changed: rebuild (the planes are re-zeroed because the row meaning changes)
+    if (sh.sym_items && sh.sym_split == p.split && sh.sym_waves == p.waves && sh.sym_taper == p.taper &&
+        sh.sym_exchange_mode == exchange_mode && sh.sym_xcd_order == c->xcd_order &&
+        (!exchange_mode || (sh.sym_tri_first == c->tri_first_pct && sh.sym_overlap == c->overlap)))
+        return 0;
+    if (sh.sym_items) {   // option changed: rebuild
         HIP_TRY(hipStreamSynchronize(sh.compute));
-        hipFree(sh.sym_items); sh.sym_items = nullptr;
+        HIP_TRY(hipStreamSynchronize(sh.compute_low));
+        HIP_TRY(hipStreamSynchronize(sh.comm));
     }
-    const int W = c->world, r = sh.rank;
-    const int tb = (int)(c->slice / MURB_SYM_BLOCK);   // blocks per slice
-    const int ts = tb * split;                          // i-side sub-blocks per slice
-    std::vector<int> flat;
-    int own = 0;
-    sym_schedule_items(W, r, tb, split, flat, &own, c->xcd_order != 0);
-    sh.sym_xcd_order = c->xcd_order;
-    std::vector<int2> items(flat.size() / 2);
-    for (size_t k = 0; k < items.size(); ++k) items[k] = make_int2(flat[2 * k], flat[2 * k + 1]);
-    MurbSymRowRanges rr{};
-    rr.nslices = W;
-    rr.blocks_per_slice = tb;
-    for (int sl = 0; sl < W; ++sl)
-        for (int k = 0; k < 3; ++k) rr.stride[sl][k] = 1;
-    // Own bodies.  Under an exchange the own-slice triangle has planes of its own (so that its row sum
-    // can run while the reduce-scatter of everything else is in flight); without one (single context)
-    // all rows of the own slice live in the big planes: j-side cells dense, i-side cells every `split`-th
-    if (!exchange_mode) {
-        rr.first[r][0] = r * ts;
-        rr.count[r][0] = ts;
-    }
-    // ... and the i-side cells of the rectangles: rows split*J of slices r+1 .. r+W/2 (cyclic, <= 2 ranges)
-    const int far = W / 2;
-    if (far > 0 && W > 1) {
-        const int a0 = r + 1, a1 = r + 1 + far;   // slices [a0, a1)
-        rr.first[r][1] = a0 * ts; rr.count[r][1] = (std::min(a1, W) - a0) * tb; rr.stride[r][1] = split;
-        if (a0 >= W) { rr.first[r][1] = (a0 - W) * ts; rr.count[r][1] = far * tb; }
-        else if (a1 > W) { rr.first[r][2] = 0; rr.count[r][2] = (a1 - W) * tb; rr.stride[r][2] = split; }
-    }
-    for (int d = 1; d <= W / 2; ++d) {
-        const int s = (r + d) % W;
-        if (s == r) continue;
-        // bodies of slice s receive j-side sums in the rows of OWN sub-blocks
-        rr.first[s][0] = r * ts;
-        rr.count[s][0] = ts;
-    }
-    sh.sym_items_own = own;
+    hipFree(sh.sym_items); sh.sym_items = nullptr;
+    free_sym_set(sh.sym_main);
+    free_sym_set(sh.sym_tri);
+    sh.bytes -= sh.sym_bytes;
+    sh.sym_bytes = 0;
+
+    SymHostLayout L;
+    plan_sym_layout(c->world, sh.rank, (int)(c->slice / MURB_SYM_BLOCK), p.split, p.waves, p.taper, exchange_mode, c->overlap,
+                    c->tri_first_pct, c->xcd_order != 0, L);
+    if (!exchange_mode && (int)L.table_main.size() != (int)(c->slots / MURB_SYM_BLOCK)) return MURBHIP_E_STATE;   // the fused row sum + integrate walks every block
+    RC_TRY(upload_sym_set(sh, sh.sym_tri, L.table_tri, L.floats_tri));
+    RC_TRY(upload_sym_set(sh, sh.sym_main, L.table_main, L.floats_main));
+    const std::vector<MurbSymItem>& items = L.items;
+    const size_t own_pieces = (size_t)L.own;
+    const int W = c->world;
+    sh.sym_items_own = (int)own_pieces;
     sh.sym_items_total = (int)items.size();
-    sh.sym_split = split;
+    sh.sym_split = p.split;
+    sh.sym_waves = p.waves;
+    sh.sym_taper = p.taper;
+    sh.sym_xcd_order = c->xcd_order;
     sh.sym_exchange_mode = exchange_mode;
-    HIP_TRY(hipMalloc((void**)&sh.sym_items, items.size() * sizeof(int2)));
-    HIP_TRY(hipMemcpy(sh.sym_items, items.data(), items.size() * sizeof(int2), hipMemcpyHostToDevice));
-    if (!sh.sym_ranges) HIP_TRY(hipMalloc((void**)&sh.sym_ranges, sizeof rr));
-    HIP_TRY(hipMemcpy(sh.sym_ranges, &rr, sizeof rr, hipMemcpyHostToDevice));
-    const size_t chunk = (size_t)3 * c->slice * sizeof(float);
-    if (!sh.sym_send) {
-        HIP_TRY(hipMalloc((void**)&sh.sym_send, chunk * W));
-        HIP_TRY(hipMalloc((void**)&sh.sym_recv, chunk));
-        HIP_TRY(hipEventCreateWithFlags(&sh.ev_rowsum, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&sh.ev_reduced, hipEventDisableTiming));
-        sh.bytes += chunk * (W + 1);
-    }
+    sh.sym_tri_first = c->tri_first_pct;
+    sh.sym_overlap = c->overlap;
+    sh.sym_t1 = L.t1;
+    HIP_TRY(hipMalloc((void**)&sh.sym_items, items.size() * sizeof(MurbSymItem)));
+    HIP_TRY(hipMemcpy(sh.sym_items, items.data(), items.size() * sizeof(MurbSymItem), hipMemcpyHostToDevice));
+    sh.sym_bytes += items.size() * sizeof(MurbSymItem);
     if (exchange_mode) {
-        const size_t tri_bytes = (size_t)3 * ts * c->slice * sizeof(float);
-        hipFree(sh.sym_tri); sh.sym_tri = nullptr;
-        HIP_TRY(hipMalloc((void**)&sh.sym_tri, tri_bytes));
-        HIP_TRY(hipMemsetAsync(sh.sym_tri, 0, tri_bytes, sh.compute));
-        if (!sh.sym_tri_acc) HIP_TRY(hipMalloc((void**)&sh.sym_tri_acc, chunk));
-        sh.bytes += tri_bytes + chunk;
+        const size_t chunk = (size_t)3 * c->slice * sizeof(float);
+        if (!sh.sym_send) {
+            HIP_TRY(hipMalloc((void**)&sh.sym_send, chunk * W));
+            HIP_TRY(hipMalloc((void**)&sh.sym_recv, chunk));
+            HIP_TRY(hipMalloc((void**)&sh.sym_tri_acc, chunk));
+            HIP_TRY(hipEventCreateWithFlags(&sh.ev_rowsum, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&sh.ev_reduced, hipEventDisableTiming));
+            sh.bytes += chunk * (W + 2);
+        }
+        // chunks of slices this rank has no rows for are never written by the row sum: they must read as 0
+        HIP_TRY(hipMemsetAsync(sh.sym_send, 0, chunk * W, sh.compute));
     }
-    // cells nobody writes must read as 0 in the row sums: zero once per layout, they stay zero
-    const size_t bytes = sym_plane_bytes(c, split);
-    if (sh.sym_part) { hipFree(sh.sym_part); sh.sym_part = nullptr; }
-    HIP_TRY(hipMalloc((void**)&sh.sym_part, bytes));
-    HIP_TRY(hipMemsetAsync(sh.sym_part, 0, bytes, sh.compute));   // on OUR stream: it is non-blocking w.r.t. stream 0
-    sh.bytes += bytes + items.size() * sizeof(int2);
+    sh.bytes += sh.sym_bytes;
     return 0;
 }
 
@@ -544,34 +669,35 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
 {
     if (count <= 0) return 0;
     if (!stream) stream = sh.compute;
+    const SymSet& st = own_triangle_planes ? sh.sym_tri : sh.sym_main;
     MurbSymArgs sa{};
     sa.rec = sh.rec[c->cur];
+    sa.part = st.part;
+    sa.comp_stride = st.comp_stride;
     sa.items = sh.sym_items;
     sa.item_first = first;
-    sa.split = sh.sym_split;
-    if (own_triangle_planes) {   // planes that cover the rank's own slice only
-        sa.part = sh.sym_tri;
-        sa.plane_block0 = sh.rank * (int)(c->slice / MURB_SYM_BLOCK);
-        sa.nrows = sh.sym_split * (int)(c->slice / MURB_SYM_BLOCK);
-        sa.row_stride = (unsigned int)c->slice;
-    } else {
-        sa.part = sh.sym_part;
-        sa.plane_block0 = 0;
-        sa.nrows = sh.sym_split * (int)(c->slots / MURB_SYM_BLOCK);
-        sa.row_stride = (unsigned int)c->slots;
-    }
     sa.soft2 = c->soft2;
     const bool timed = stream == sh.compute && !potential;   // the profiling events live on the main compute stream
     if (timed) RC_TRY(prof_begin(c, sh));
-    if (potential)   // murbhip_energy's sweep: phi into plane 0
-        hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1, 1>), dim3((unsigned)count), dim3(256), 0, stream, sa);
-    else if (c->plan_waves == 8)
-        hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1>), dim3((unsigned)count), dim3(512), 0, stream, sa);
-    else
-        hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1>), dim3((unsigned)count), dim3(256), 0, stream, sa);
+    if (sh.sym_waves == 8) {
+        if (potential) hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1, 1>), dim3((unsigned)count), dim3(512), 0, stream, sa);
+        else hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1>), dim3((unsigned)count), dim3(512), 0, stream, sa);
+    } else {
+        if (potential) hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1, 1>), dim3((unsigned)count), dim3(256), 0, stream, sa);
+        else hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1>), dim3((unsigned)count), dim3(256), 0, stream, sa);
+    }
     RC_TRY(hip_rc(hipGetLastError()));
     if (timed) RC_TRY(prof_end(c, sh));
     return 0;
+}
+
+// row sum of a set's partial rows into `out` (chunks of [3][out_slice_slots])
+int enqueue_sym_rowsum(const SymSet& st, float* out, unsigned int out_slice_slots, hipStream_t stream)
+{
+    if (st.nblocks <= 0) return 0;
+    hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)st.nblocks * (MURB_SYM_BLOCK / 64)), dim3(MURB_ROWSUM_THREADS), 0, stream,
+                       st.part, st.comp_stride, st.rows, out, out_slice_slots);
+    return hip_rc(hipGetLastError());
 }
 
 // One iteration under the half-ring schedule.  Per shard, on the compute stream unless noted:
@@ -589,32 +715,29 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
 int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int update_state)
 {
     const unsigned int chunk_floats = (unsigned int)(3 * c->slice);
-    const int rows_all = (int)(c->slots / MURB_SYM_BLOCK), rows_own = (int)(c->slice / MURB_SYM_BLOCK);
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
-        RC_TRY(build_sym_schedule(c, sh, p.split));
+        RC_TRY(build_sym_schedule(c, sh, p));
         if (is_idle(c, sh)) continue;   // "solo_shard" timing aid: idle shards enqueue nothing at all
-        const int own = sh.sym_items_own, t1 = c->overlap == 1 ? (int)((long)own * c->tri_first_pct / 100) : 0;
+        const int own = sh.sym_items_own, t1 = sh.sym_t1;
         if (c->overlap == 2) {
             // the whole own-slice triangle on a second, lowest-priority compute stream: it runs alone while
             // the positions are still being gathered, then fills the gaps and the tail of the rectangles
             if (c->gather_pending || c->reduce_pending) HIP_TRY(hipStreamWaitEvent(sh.compute_low, sh.ev_integrated, 0));
             RC_TRY(enqueue_sym_launch(c, sh, 0, own, true, sh.compute_low));
-            hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slice / 64)), dim3(MURB_ROWSUM_THREADS), 0, sh.compute_low,
-                               sh.sym_tri, sh.sym_split * rows_own, (unsigned int)c->slice,
-                               (const MurbSymRowRanges*)nullptr, sh.sym_split, sh.sym_tri_acc);
-            RC_TRY(hip_rc(hipGetLastError()));
+            RC_TRY(enqueue_sym_rowsum(sh.sym_tri, sh.sym_tri_acc, (unsigned int)c->slice, sh.compute_low));
             HIP_TRY(hipEventRecord(sh.ev_tri, sh.compute_low));
         }
         RC_TRY(enqueue_sym_launch(c, sh, 0, t1, true));
         if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
         RC_TRY(enqueue_sym_launch(c, sh, own, sh.sym_items_total - own, false));
-        if (c->exchange == 0 && c->reduce_pending)   // peer-read reduce: nobody may still be reading our send buffer
-            for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.compute, peer.ev_reduced, 0));
-        hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slots / 64)), dim3(MURB_ROWSUM_THREADS), 0, sh.compute,
-                           sh.sym_part, sh.sym_split * rows_all, (unsigned int)c->slots, sh.sym_ranges, sh.sym_split,
-                           sh.sym_send);
-        RC_TRY(hip_rc(hipGetLastError()));
+        // nobody may still be reading our send buffer: the peer-read sums of the previous step (one process), or our
+        // own previous reduce-scatter (RCCL reads it on the comm stream)
+        if (c->reduce_pending) {
+            if (c->exchange == 0) for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.compute, peer.ev_reduced, 0));
+            else HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
+        }
+        RC_TRY(enqueue_sym_rowsum(sh.sym_main, sh.sym_send, (unsigned int)c->slice, sh.compute));
         HIP_TRY(hipEventRecord(sh.ev_rowsum, sh.compute));
         c->interactions_per_launch = (double)sh.count * (double)c->n;
     }
@@ -651,15 +774,12 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
         HIP_TRY(hipSetDevice(sh.device));
         HIP_TRY(hipEventRecord(sh.ev_reduced, sh.comm));
         // meanwhile: the rest of the own-slice triangle and its row sum
-        const int own = sh.sym_items_own, t1 = c->overlap == 1 ? (int)((long)own * c->tri_first_pct / 100) : 0;
+        const int own = sh.sym_items_own, t1 = sh.sym_t1;
         if (c->overlap == 2) {
             HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_tri, 0));
         } else {
             RC_TRY(enqueue_sym_launch(c, sh, t1, own - t1, true));
-            hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slice / 64)), dim3(MURB_ROWSUM_THREADS), 0, sh.compute,
-                               sh.sym_tri, sh.sym_split * rows_own, (unsigned int)c->slice,
-                               (const MurbSymRowRanges*)nullptr, sh.sym_split, sh.sym_tri_acc);
-            RC_TRY(hip_rc(hipGetLastError()));
+            RC_TRY(enqueue_sym_rowsum(sh.sym_tri, sh.sym_tri_acc, (unsigned int)c->slice, sh.compute));
         }
         HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
         MurbIntegrateArgs a{};
@@ -731,6 +851,28 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
     return 0;
 }
 
+// The compute streams of a shard.  reserve > 0: created with a CU mask that leaves out the `reserve` highest-numbered
+// CUs.  The force kernels fill every CU they may use (4 waves per SIMD, 120 VGPRs each), and stream priority does
+// not pre-empt resident workgroups: a collective's kernel would otherwise wait for a workgroup to retire before it can
+// start.  Bit b of the mask is CU b / 8 of XCD b % 8 (the driver deals the mask's bits to the XCDs round-robin), so
+// 8 reserved CUs are one per XCD, 16 two per XCD.  hipExtStreamCreateWithCUMask has no flags argument: such a stream
+// has the default (blocking with respect to stream 0) flag, harmless here since the library never uses stream 0.
+int create_compute_streams(const murbhip_ctx* c, Shard& sh, int reserve)
+{
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (reserve > 0 && c->cu_count > reserve) {
+        std::vector<uint32_t> mask((size_t)(c->cu_count + 31) / 32, 0u);
+        for (int b = 0; b < c->cu_count - reserve; ++b) mask[(size_t)b / 32] |= 1u << (b % 32);
+        HIP_TRY(hipExtStreamCreateWithCUMask(&sh.compute, (uint32_t)mask.size(), mask.data()));
+        HIP_TRY(hipExtStreamCreateWithCUMask(&sh.compute_low, (uint32_t)mask.size(), mask.data()));
+        return 0;
+    }
+    HIP_TRY(hipStreamCreateWithFlags(&sh.compute, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithPriority(&sh.compute_low, hipStreamNonBlocking, least));
+    return 0;
+}
+
 int create_common(murbhip_ctx** out, unsigned long n, float soft, float g, int world, int nlocal, const int* devices,
                   const int* ranks, int exchange, bool rank_mode)
 {
@@ -763,7 +905,7 @@ int create_common(murbhip_ctx** out, unsigned long n, float soft, float g, int w
         sh.rank = ranks[i];
         partition(n, world, sh.rank, &sh.first, &sh.count);
         if ((rc = hip_rc(hipSetDevice(sh.device)))) break;
-        if ((rc = hip_rc(hipStreamCreateWithFlags(&sh.compute, hipStreamNonBlocking)))) break;
+        if ((rc = create_compute_streams(c, sh, 0))) break;
         // the exchange stream gets the highest priority: its (few, small) collective kernels must be
         // dispatched as soon as they are ready although the force kernel keeps every CU full
         {
@@ -771,26 +913,18 @@ int create_common(murbhip_ctx** out, unsigned long n, float soft, float g, int w
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
             if ((rc = hip_rc(hipStreamCreateWithPriority(&sh.comm, hipStreamNonBlocking, greatest)))) break;
         }
-        {
-            int least = 0, greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            if ((rc = hip_rc(hipStreamCreateWithPriority(&sh.compute_low, hipStreamNonBlocking, least)))) break;
-        }
         if ((rc = hip_rc(hipEventCreateWithFlags(&sh.ev_tri, hipEventDisableTiming)))) break;
         if ((rc = hip_rc(hipEventCreateWithFlags(&sh.ev_integrated, hipEventDisableTiming)))) break;
         if ((rc = hip_rc(hipEventCreateWithFlags(&sh.ev_gathered, hipEventDisableTiming)))) break;
         const size_t rec_bytes = c->slots * sizeof(float4);
         const size_t vel_bytes = c->slice * sizeof(float4);
-        const size_t accp_bytes = (size_t)kMaxParts * c->slice * sizeof(float4);
         const size_t acco_bytes = 3 * c->slice * sizeof(float);
         if ((rc = hip_rc(hipMalloc((void**)&sh.rec[0], rec_bytes)))) break;
         if ((rc = hip_rc(hipMalloc((void**)&sh.rec[1], rec_bytes)))) break;
         if ((rc = hip_rc(hipMalloc((void**)&sh.vel, vel_bytes)))) break;
-        if ((rc = hip_rc(hipMalloc((void**)&sh.accp, accp_bytes)))) break;
         if ((rc = hip_rc(hipMalloc((void**)&sh.acc_out, acco_bytes)))) break;
-        if ((rc = hip_rc(hipMemset(sh.accp, 0, accp_bytes)))) break;
         if ((rc = hip_rc(hipMemset(sh.acc_out, 0, acco_bytes)))) break;
-        sh.bytes = 2 * rec_bytes + vel_bytes + accp_bytes + acco_bytes;
+        sh.bytes = 2 * rec_bytes + vel_bytes + acco_bytes;
     }
     // peer access for the copy exchange between distinct devices
     if (rc == 0 && world > 1 && !rank_mode && exchange == 0) {
@@ -898,6 +1032,46 @@ int murbhip_schedule_items(unsigned long n, int world, int rank, int split, int*
     return 0;
 }
 
+int murbhip_schedule_layout(unsigned long n, int world, int rank, int split, int waves, int taper_pct, int tri_first_pct,
+                            int exchange_mode, long* items, unsigned long item_capacity, unsigned long* item_count, long* rows,
+                            unsigned long row_capacity, unsigned long* row_count, unsigned long* floats_main,
+                            unsigned long* floats_tri)
+{
+    if (world < 1 || world > MURB_SYM_MAX_RANKS || rank < 0 || rank >= world || !item_count || !row_count) return MURBHIP_E_INVALID;
+    if (split != 1 && split != 2 && split != 4 && split != 8 && split != 16) return MURBHIP_E_INVALID;
+    if ((waves != 4 && waves != 8) || taper_pct < 0 || taper_pct > 100 || tri_first_pct < 0 || tri_first_pct > 100) return MURBHIP_E_INVALID;
+    if (MURB_SYM_BLOCK / split < 16 * waves) return MURBHIP_E_INVALID;
+    SymHostLayout L;
+    plan_sym_layout(world, rank, (int)(slice_slots(n, world) / MURB_SYM_BLOCK), split, waves, taper_pct, exchange_mode != 0 || world > 1, 1,
+                    tri_first_pct, false, L);
+    *item_count = L.items.size();
+    *row_count = L.table_main.size() + L.table_tri.size();
+    if (floats_main) *floats_main = L.floats_main;
+    if (floats_tri) *floats_tri = L.floats_tri;
+    if (items) {
+        if (item_capacity < L.items.size()) return MURBHIP_E_INVALID;
+        const bool ex = exchange_mode != 0 || world > 1;
+        for (size_t k = 0; k < L.items.size(); ++k) {
+            const MurbSymItem& it = L.items[k];
+            long* o = items + 8 * k;
+            o[0] = it.i_slot0; o[1] = (long)it.ngroups * waves * MURB_SYM_R; o[2] = it.J; o[3] = it.flags;
+            o[4] = (ex && (int)k < L.own) ? 1 : 0;
+            o[5] = (long)it.ioff; o[6] = (long)it.joff;
+            o[7] = !ex ? 0 : ((int)k < L.t1 ? 0 : ((int)k < L.own ? 1 : 2));
+        }
+    }
+    if (rows) {
+        if (row_capacity < *row_count) return MURBHIP_E_INVALID;
+        size_t e = 0;
+        for (int set = 0; set < 2; ++set)
+            for (const MurbSymBlockRows& br : (set == 0 ? L.table_main : L.table_tri)) {
+                long* o = rows + 7 * e++;
+                o[0] = set; o[1] = br.out_slice; o[2] = br.out_block; o[3] = (long)br.base_i; o[4] = br.ni; o[5] = (long)br.base_j; o[6] = br.nj;
+            }
+    }
+    return 0;
+}
+
 int murbhip_device_count(int* count)
 {
     if (!count) return MURBHIP_E_INVALID;
@@ -946,7 +1120,7 @@ int murbhip_create_rank(murbhip_ctx** out, unsigned long n, float soft, float g,
                         const void* unique_id)
 {
     if (world < 1 || rank < 0 || rank >= world || (unsigned long)world > n) return MURBHIP_E_INVALID;
-    if (world > MURB_SYM_MAX_RANKS) return MURBHIP_E_INVALID;   // fixed-size per-slice tables (MurbSymRowRanges, MurbPeerPtrs)
+    if (world > MURB_SYM_MAX_RANKS) return MURBHIP_E_INVALID;   // fixed-size per-rank tables (MurbPeerPtrs)
     if (world > 1 && !unique_id) return MURBHIP_E_INVALID;
     if ((world > 1 || unique_id) && !rccl().ok) return MURBHIP_E_NO_RCCL;
     RC_TRY(create_common(out, n, soft, g, world, 1, &device, &rank, 1, true));
@@ -975,9 +1149,9 @@ int murbhip_destroy(murbhip_ctx* c)
         if (sh.ev_gathered) hipEventDestroy(sh.ev_gathered);
         if (sh.compute) hipStreamDestroy(sh.compute);
         if (sh.comm) hipStreamDestroy(sh.comm);
-        hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out); hipFree(sh.phi_out); hipFree(sh.mass); hipFree(sh.metrics); hipFree(sh.sym_part);
-        hipFree(sh.sym_items); hipFree(sh.sym_ranges); hipFree(sh.sym_send); hipFree(sh.sym_recv);
-        hipFree(sh.sym_tri); hipFree(sh.sym_tri_acc);
+        hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out); hipFree(sh.phi_out); hipFree(sh.mass); hipFree(sh.metrics);
+        hipFree(sh.sym_items); free_sym_set(sh.sym_main); free_sym_set(sh.sym_tri);
+        hipFree(sh.sym_send); hipFree(sh.sym_recv); hipFree(sh.sym_tri_acc);
         if (sh.ev_rowsum) hipEventDestroy(sh.ev_rowsum);
         if (sh.ev_reduced) hipEventDestroy(sh.ev_reduced);
     }
@@ -1157,6 +1331,7 @@ int murbhip_integrate_host_acc(murbhip_ctx* c, const float* ax, const float* ay,
         std::fill(part.begin(), part.end(), make_float4(0.f, 0.f, 0.f, 0.f));
         for (unsigned long k = 0; k < sh.count; ++k)
             part[k] = make_float4(ax[sh.first + k], ay[sh.first + k], az[sh.first + k], 0.f);
+        RC_TRY(ensure_accp(c, sh));
         HIP_TRY(hipMemcpyAsync(sh.accp, part.data(), part.size() * sizeof(float4), hipMemcpyHostToDevice, sh.compute));
         HIP_TRY(hipStreamSynchronize(sh.compute));   // `part` is reused for the next shard
         RC_TRY(enqueue_integrate(c, sh, 1, dt, 1, nullptr, 0));
@@ -1242,12 +1417,9 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
         }
         if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
         if (symmetric_sweep) {
-            RC_TRY(build_sym_schedule(c, sh, main_plan.split));
+            RC_TRY(build_sym_schedule(c, sh, main_plan));
             RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_total, false, nullptr, true));
-            hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)(c->slots / 64)), dim3(MURB_ROWSUM_THREADS), 0, sh.compute,
-                               sh.sym_part, sh.sym_split * (int)(c->slots / MURB_SYM_BLOCK), (unsigned int)c->slots,
-                               (const MurbSymRowRanges*)nullptr, sh.sym_split, sh.phi_out);
-            RC_TRY(hip_rc(hipGetLastError()));
+            RC_TRY(enqueue_sym_rowsum(sh.sym_main, sh.phi_out, (unsigned int)c->slots, sh.compute));
             continue;
         }
         RC_TRY(enqueue_force(c, sh, p, 0));
@@ -1281,6 +1453,8 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     else if (k == "jsplit") { if (value < 0 || value > kMaxParts / 2) return MURBHIP_E_INVALID; c->jsplit = (int)value; }
     else if (k == "xcd_order") c->xcd_order = value ? 1 : 0;
     else if (k == "tri_first_pct") { if (value < 0 || value > 100) return MURBHIP_E_INVALID; c->tri_first_pct = (int)value; }
+    else if (k == "taper") { if (value < -1 || value > 100) return MURBHIP_E_INVALID; c->taper = (int)value; }
+    else if (k == "taper") { if (value < -1 || value > 100) return MURBHIP_E_INVALID; c->taper = (int)value; }
     else if (k == "sym_waves") { if (value != 0 && value != 4 && value != 8) return MURBHIP_E_INVALID; c->sym_waves = (int)value; }
     else if (k == "overlap") { if (value < 0 || value > 2) return MURBHIP_E_INVALID; c->overlap = (int)value; }
     else if (k == "integrator") {
@@ -1289,6 +1463,19 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
         c->integrator = (int)value;
     }
     else if (k == "solo_shard") c->solo_shard = (int)value;
+    else if (k == "cu_reserve") {
+        if (value < 0 || value > c->cu_count / 2) return MURBHIP_E_INVALID;
+        if ((int)value != c->cu_reserve) {
+            RC_TRY(murbhip_sync(c));
+            for (Shard& sh : c->shards) {
+                HIP_TRY(hipSetDevice(sh.device));
+                HIP_TRY(hipStreamDestroy(sh.compute)); sh.compute = nullptr;
+                HIP_TRY(hipStreamDestroy(sh.compute_low)); sh.compute_low = nullptr;
+                RC_TRY(create_compute_streams(c, sh, (int)value));
+            }
+            c->cu_reserve = (int)value;
+        }
+    }
     else if (k == "force_exchange") {
         if (value && c->exchange == 1 && !c->shards[0].comm_rccl) return MURBHIP_E_STATE;
         c->force_exchange = value ? 1 : 0;
@@ -1317,6 +1504,7 @@ int murbhip_get_info(murbhip_ctx* c, const char* key, double* value)
     else if (k == "n") *value = (double)c->n;
     else if (k == "slots") *value = (double)c->slots;
     else if (k == "world") *value = c->world;
+    else if (k == "cu_reserve") *value = c->cu_reserve;
     else if (k == "rank") *value = c->shards[0].rank;
     else if (k == "jsplit") *value = p.persistent ? (double)p.sched[0].nblocks / std::max(resident_blocks(c), 1)
                                                   : (double)(p.parts_local + p.parts_remote);

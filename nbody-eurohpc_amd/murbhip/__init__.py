@@ -45,6 +45,9 @@ def lib():
         L.murbhip_slot_of_body.argtypes = [C.c_ulong, C.c_int, C.c_ulong]
         L.murbhip_schedule_items.argtypes = [C.c_ulong, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_ulong,
                                              C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]
+        L.murbhip_schedule_layout.argtypes = [C.c_ulong] + [C.c_int] * 7 + [C.POINTER(C.c_long), C.c_ulong, C.POINTER(C.c_ulong),
+                                                                            C.POINTER(C.c_long), C.c_ulong, C.POINTER(C.c_ulong),
+                                                                            C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]
         L.murbhip_device_count.argtypes = [C.POINTER(C.c_int)]
         L.murbhip_create.argtypes = [C.POINTER(C.c_void_p), C.c_ulong, C.c_float, C.c_float, C.c_int]
         L.murbhip_create_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_ulong, C.c_float, C.c_float, C.c_int,
@@ -70,7 +73,7 @@ def lib():
 
 
 EXPORTS = ("murbhip_version murbhip_error_string murbhip_partition murbhip_slice_slots murbhip_slot_of_body "
-           "murbhip_schedule_items "
+           "murbhip_schedule_items murbhip_schedule_layout "
            "murbhip_device_count murbhip_create murbhip_create_sharded murbhip_unique_id murbhip_create_rank "
            "murbhip_destroy murbhip_upload murbhip_download_state murbhip_download_acc murbhip_compute_acc "
            "murbhip_step murbhip_steps murbhip_integrate_host_acc murbhip_sync murbhip_energy murbhip_moments murbhip_set_option "
@@ -119,6 +122,21 @@ def schedule_items(n, world, rank, split=1):
     _check(lib().murbhip_schedule_items(n, world, rank, split, items.ctypes.data_as(C.POINTER(C.c_int)), count.value,
                                         C.byref(count), C.byref(own)), "murbhip_schedule_items")
     return items, own.value
+
+
+def schedule_layout(n, world, rank, split=1, waves=4, taper=0, tri_first_pct=50, exchange_mode=False):
+    """(items, rows, floats_main, floats_tri): the pair-symmetric work list with its partial-row layout, as arrays of
+    8 longs per item and 7 per row-table entry (include/murbhip.h: murbhip_schedule_layout)."""
+    ni, nr, fm, ft = C.c_ulong(), C.c_ulong(), C.c_ulong(), C.c_ulong()
+    args = (n, world, rank, split, waves, taper, tri_first_pct, int(exchange_mode))
+    _check(lib().murbhip_schedule_layout(*args, None, 0, C.byref(ni), None, 0, C.byref(nr), C.byref(fm), C.byref(ft)),
+           "murbhip_schedule_layout")
+    items = np.zeros((ni.value, 8), np.int64)
+    rows = np.zeros((nr.value, 7), np.int64)
+    lp = C.POINTER(C.c_long)
+    _check(lib().murbhip_schedule_layout(*args, items.ctypes.data_as(lp), ni.value, C.byref(ni), rows.ctypes.data_as(lp), nr.value,
+                                         C.byref(nr), C.byref(fm), C.byref(ft)), "murbhip_schedule_layout")
+    return items, rows, fm.value, ft.value
 
 
 def device_count():

@@ -1,9 +1,19 @@
 // TEST INFRASTRUCTURE — a stand-in for librccl that lets SEVERAL PROCESSES ON ONE GPU run the library's
 // one-process-per-GPU path (murbhip_create_rank: rank > 0, world > 1), which real RCCL refuses ("duplicate
 // GPU").  Same entry points and argument meaning as the ncclXxx functions libmurbhip binds at run time
-// (csrc/murb_rccl.h); the collectives go through a POSIX shared-memory segment and a process-shared
-// barrier, synchronously: each call drains the stream it is given, stages through host memory, and returns
-// when the result is in place.  Loaded only when MURBHIP_RCCL_LIBRARY points at it (tests/test_rank_mode_mock.py).
+// (csrc/murb_rccl.h); the data moves through host memory (a POSIX shared-memory segment between processes).
+//
+// Two modes (environment variable MURB_MOCK_MODE):
+//   async (default)  like real RCCL, a call only ENQUEUES work on the stream it is given and returns: a
+//                    device->host copy of the caller's contribution, a host function that meets the other
+//                    ranks at a process-shared barrier (and, for the reduce-scatter, adds the blocks up), a
+//                    host->device copy of the result, a second barrier (the staging area is free again).
+//                    Nothing is drained: a consumer that forgets to wait for the collective's stream reads
+//                    stale data and the comparison with the single-GPU run fails — the property a synchronous
+//                    stand-in cannot check.
+//   sync             each call drains its stream, stages through host memory and returns when the result
+//                    is in place (the behaviour of round 1).
+// Loaded only when MURBHIP_RCCL_LIBRARY points at it (tests/test_rank_mode_mock.py).
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <pthread.h>
@@ -11,8 +21,10 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -32,14 +44,25 @@ struct Comm {
     std::string name;
     LocalGroup* local = nullptr;
     int device = 0;
+    bool pinned = false;
 };
 struct PendingOp {
     int kind;   // 0 all-gather, 1 reduce-scatter
     const void* send; void* recv; size_t count; Comm* comm; hipStream_t stream;
 };
+// one process, several ranks: a ring of pinned staging buffers, each guarded by the events of its last use
+struct Staging {
+    float* host = nullptr;
+    size_t floats = 0;
+    std::vector<hipEvent_t> done;   // one per rank: recorded after that rank's host->device copy
+    bool used = false;
+};
 struct LocalGroup {
     int nranks = 0, alive = 0;
     std::vector<PendingOp> pending;
+    Staging ring[4];
+    int next = 0;
+    std::vector<hipEvent_t> copied;   // per rank: its contribution has reached the staging buffer
 };
 int group_depth = 0;
 std::vector<LocalGroup*> touched;   // groups with pending work inside the current ncclGroupStart/End
@@ -53,6 +76,51 @@ std::string segment_name(const Id& id)
     return buf;
 }
 constexpr int kOk = 0, kInvalid = 4, kSystem = 2;
+
+bool async_mode()
+{
+    static const bool a = [] {
+        const char* m = std::getenv("MURB_MOCK_MODE");
+        return !(m && std::string(m) == "sync");
+    }();
+    return a;
+}
+
+// ---- host functions (hipLaunchHostFunc): no HIP call inside
+void host_barrier(void* p) { pthread_barrier_wait(&static_cast<Comm*>(p)->seg->barrier); }
+
+struct ReduceJob { Comm* c; size_t recvcount; };
+// result area of rank r: behind the nranks contributions
+inline float* reduce_result(Comm* c, size_t recvcount)
+{
+    const size_t block = recvcount * 4, mine = block * c->nranks;
+    return reinterpret_cast<float*>(c->seg->data + mine * c->nranks + (size_t)c->rank * block);
+}
+void host_reduce(void* p)
+{
+    ReduceJob* j = static_cast<ReduceJob*>(p);
+    Comm* c = j->c;
+    const size_t block = j->recvcount * 4, mine = block * c->nranks;
+    float* out = reduce_result(c, j->recvcount);
+    for (size_t k = 0; k < j->recvcount; ++k) out[k] = 0.f;
+    for (int r = 0; r < c->nranks; ++r) {   // rank order: reproducible
+        const float* src = reinterpret_cast<const float*>(c->seg->data + (size_t)r * mine + (size_t)c->rank * block);
+        for (size_t k = 0; k < j->recvcount; ++k) out[k] += src[k];
+    }
+    delete j;
+}
+
+struct LocalReduceJob { const float* staged; float* out; size_t count; int nranks, rank; };
+void host_local_reduce(void* p)
+{
+    LocalReduceJob* j = static_cast<LocalReduceJob*>(p);
+    for (size_t k = 0; k < j->count; ++k) j->out[k] = 0.f;
+    for (int r = 0; r < j->nranks; ++r) {
+        const float* src = j->staged + ((size_t)r * j->nranks + (size_t)j->rank) * j->count;
+        for (size_t k = 0; k < j->count; ++k) j->out[k] += src[k];
+    }
+    delete j;
+}
 }  // namespace
 
 extern "C" {
@@ -105,12 +173,15 @@ int ncclCommInitRank(void** out, int nranks, Id id, int rank)
         for (int tries = 0; tries < 20000 && c->seg->ready.load() != 1; ++tries) usleep(1000);
         if (c->seg->ready.load() != 1 || c->seg->nranks != nranks) { delete c; return kSystem; }
     }
+    // pinned: the copies of the async mode are then truly asynchronous (unpinned they still run in stream order)
+    if (async_mode()) c->pinned = hipHostRegister(c->seg->data, kCapacity, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
     pthread_barrier_wait(&c->seg->barrier);
     *out = c;
     return kOk;
 }
 
-// one process, several "devices" (the same ordinal may repeat): the collectives are executed at ncclGroupEnd,
+// one process, several "devices" (the same ordinal may repeat): the collectives are issued at ncclGroupEnd,
 // when every rank's call has been recorded
 int ncclCommInitAll(void** out, int ndev, const int* devices)
 {
@@ -130,11 +201,21 @@ int ncclCommDestroy(void* comm)
     Comm* c = static_cast<Comm*>(comm);
     if (!c) return kOk;
     if (c->local) {
-        if (--c->local->alive == 0) delete c->local;
+        if (--c->local->alive == 0) {
+            (void)hipDeviceSynchronize();
+            for (Staging& s : c->local->ring) {
+                if (s.host) (void)hipHostFree(s.host);
+                for (hipEvent_t e : s.done) (void)hipEventDestroy(e);
+            }
+            for (hipEvent_t e : c->local->copied) (void)hipEventDestroy(e);
+            delete c->local;
+        }
         delete c;
         return kOk;
     }
+    (void)hipDeviceSynchronize();   // async mode: host functions of this communicator may still be queued
     pthread_barrier_wait(&c->seg->barrier);
+    if (c->pinned) (void)hipHostUnregister(c->seg->data);
     munmap(c->seg, sizeof(Segment) + kCapacity);
     if (c->rank == 0) shm_unlink(c->name.c_str());
     delete c;
@@ -153,6 +234,13 @@ int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* c
         return kOk;
     }
     if (!c || dtype != 7 || bytes * c->nranks > kCapacity) return kInvalid;
+    if (async_mode()) {
+        if (hipMemcpyAsync(c->seg->data + (size_t)c->rank * bytes, send, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return kSystem;
+        if (hipLaunchHostFunc(stream, host_barrier, c) != hipSuccess) return kSystem;
+        if (hipMemcpyAsync(recv, c->seg->data, bytes * c->nranks, hipMemcpyHostToDevice, stream) != hipSuccess) return kSystem;
+        if (hipLaunchHostFunc(stream, host_barrier, c) != hipSuccess) return kSystem;
+        return kOk;
+    }
     if (hipStreamSynchronize(stream) != hipSuccess) return kSystem;
     if (hipMemcpy(c->seg->data + (size_t)c->rank * bytes, send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return kSystem;
     pthread_barrier_wait(&c->seg->barrier);
@@ -171,8 +259,17 @@ int ncclReduceScatter(const void* send, void* recv, size_t recvcount, int dtype,
         touched.push_back(c->local);
         return kOk;
     }
+    if (!c) return kInvalid;
     const size_t block = recvcount * 4, mine = block * c->nranks;
-    if (!c || dtype != 7 || op != 0 || mine * c->nranks > kCapacity) return kInvalid;
+    if (dtype != 7 || op != 0 || mine * c->nranks + block * c->nranks > kCapacity) return kInvalid;
+    if (async_mode()) {
+        if (hipMemcpyAsync(c->seg->data + (size_t)c->rank * mine, send, mine, hipMemcpyDeviceToHost, stream) != hipSuccess) return kSystem;
+        if (hipLaunchHostFunc(stream, host_barrier, c) != hipSuccess) return kSystem;
+        if (hipLaunchHostFunc(stream, host_reduce, new ReduceJob{c, recvcount}) != hipSuccess) return kSystem;
+        if (hipMemcpyAsync(recv, reduce_result(c, recvcount), block, hipMemcpyHostToDevice, stream) != hipSuccess) return kSystem;
+        if (hipLaunchHostFunc(stream, host_barrier, c) != hipSuccess) return kSystem;
+        return kOk;
+    }
     if (hipStreamSynchronize(stream) != hipSuccess) return kSystem;
     if (hipMemcpy(c->seg->data + (size_t)c->rank * mine, send, mine, hipMemcpyDeviceToHost) != hipSuccess) return kSystem;
     pthread_barrier_wait(&c->seg->barrier);
@@ -186,15 +283,13 @@ int ncclReduceScatter(const void* send, void* recv, size_t recvcount, int dtype,
     return kOk;
 }
 
-static int run_local(LocalGroup* g)
+// one process, several ranks, synchronous form
+static int run_local_sync(LocalGroup* g)
 {
-    if (g->pending.empty()) return kOk;
-    if ((int)g->pending.size() != g->nranks) return kInvalid;   // every rank must have made the same single call
     const int kind = g->pending[0].kind;
     const size_t count = g->pending[0].count, n = (size_t)g->nranks;
     std::vector<std::vector<float>> host(n);
     for (const PendingOp& op : g->pending) {
-        if (op.kind != kind || op.count != count) return kInvalid;
         const size_t floats = kind == 0 ? count : count * n;
         host[op.comm->rank].resize(floats);
         if (hipSetDevice(op.comm->device) != hipSuccess || hipStreamSynchronize(op.stream) != hipSuccess ||
@@ -212,8 +307,75 @@ static int run_local(LocalGroup* g)
             hipMemcpy(op.recv, out.data(), out.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
             return kSystem;
     }
-    g->pending.clear();
     return kOk;
+}
+
+// ... asynchronous form: copies and host functions on the ranks' own streams, ordered by events.  Staging layout:
+// all-gather [rank][count]; reduce-scatter [rank][nranks][count] followed by the results [rank][count].
+static int run_local_async(LocalGroup* g)
+{
+    const int kind = g->pending[0].kind;
+    const size_t count = g->pending[0].count, n = (size_t)g->nranks;
+    const size_t per_rank = kind == 0 ? count : count * n;
+    const size_t need = per_rank * n + (kind == 1 ? count * n : 0);
+    Staging& st = g->ring[g->next];
+    g->next = (g->next + 1) % 4;
+    if (st.used)   // its previous collective (four calls ago) must have left the buffer
+        for (hipEvent_t e : st.done)
+            if (hipEventSynchronize(e) != hipSuccess) return kSystem;
+    if (st.floats < need) {
+        if (st.host) (void)hipHostFree(st.host);
+        if (hipHostMalloc((void**)&st.host, need * 4, hipHostMallocDefault) != hipSuccess) return kSystem;
+        st.floats = need;
+    }
+    if (st.done.empty()) {
+        st.done.resize(n);
+        for (hipEvent_t& e : st.done)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return kSystem;
+    }
+    if (g->copied.empty()) {
+        g->copied.resize(n);
+        for (hipEvent_t& e : g->copied)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return kSystem;
+    }
+    for (const PendingOp& op : g->pending) {
+        const int r = op.comm->rank;
+        if (hipSetDevice(op.comm->device) != hipSuccess ||
+            hipMemcpyAsync(st.host + (size_t)r * per_rank, op.send, per_rank * 4, hipMemcpyDeviceToHost, op.stream) != hipSuccess ||
+            hipEventRecord(g->copied[r], op.stream) != hipSuccess)
+            return kSystem;
+    }
+    for (const PendingOp& op : g->pending) {
+        const int r = op.comm->rank;
+        if (hipSetDevice(op.comm->device) != hipSuccess) return kSystem;
+        for (size_t k = 0; k < n; ++k)
+            if (hipStreamWaitEvent(op.stream, g->copied[k], 0) != hipSuccess) return kSystem;
+        const float* src = st.host;
+        size_t floats = count * n;
+        if (kind == 1) {
+            float* out = st.host + per_rank * n + (size_t)r * count;
+            if (hipLaunchHostFunc(op.stream, host_local_reduce, new LocalReduceJob{st.host, out, count, (int)n, r}) != hipSuccess)
+                return kSystem;
+            src = out;
+            floats = count;
+        }
+        if (hipMemcpyAsync(op.recv, src, floats * 4, hipMemcpyHostToDevice, op.stream) != hipSuccess ||
+            hipEventRecord(st.done[r], op.stream) != hipSuccess)
+            return kSystem;
+    }
+    st.used = true;
+    return kOk;
+}
+
+static int run_local(LocalGroup* g)
+{
+    if (g->pending.empty()) return kOk;
+    if ((int)g->pending.size() != g->nranks) return kInvalid;   // every rank must have made the same single call
+    for (const PendingOp& op : g->pending)
+        if (op.kind != g->pending[0].kind || op.count != g->pending[0].count) return kInvalid;
+    const int rc = async_mode() ? run_local_async(g) : run_local_sync(g);
+    g->pending.clear();
+    return rc;
 }
 
 int ncclGroupStart() { ++group_depth; return kOk; }
@@ -221,8 +383,11 @@ int ncclGroupEnd()
 {
     if (group_depth > 0 && --group_depth == 0) {
         int rc = kOk;
-        for (LocalGroup* g : touched) { const int r = run_local(g); if (r != kOk) rc = r; }
+        std::vector<LocalGroup*> groups;
+        for (LocalGroup* g : touched)
+            if (std::find(groups.begin(), groups.end(), g) == groups.end()) groups.push_back(g);
         touched.clear();
+        for (LocalGroup* g : groups) { const int r = run_local(g); if (r != kOk) rc = r; }
         return rc;
     }
     return kOk;

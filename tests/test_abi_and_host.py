@@ -171,6 +171,78 @@ def test_half_ring_schedule_covers_every_pair_once(mh, n, world, split):
         assert max(counts) - min(counts) <= split * tb, counts     # balanced up to one block row
 
 
+@pytest.mark.parametrize("n,world,split,waves,taper,exchange", [
+    (5000, 1, 1, 4, 0, False), (5000, 1, 4, 4, 0, False), (9000, 1, 8, 8, 0, False), (9000, 1, 2, 4, 50, False),
+    (9000, 1, 8, 8, 40, False), (3000, 1, 1, 4, 0, True),      # one rank with the exchange pipeline (RCCL self-test)
+    (9000, 2, 1, 4, 0, True), (9001, 3, 2, 4, 30, True), (20000, 4, 4, 4, 0, True), (20000, 4, 2, 8, 60, True),
+    (30000, 5, 1, 4, 0, True), (60000, 8, 4, 4, 25, True),
+])
+def test_pair_symmetric_layout_is_complete_and_collision_free(mh, n, world, split, waves, taper, exchange):
+    """What the pair-symmetric kernel is handed (murbhip_schedule_layout, host only), for every rank of a run:
+      * every ordered (i, j) interaction is applied exactly once over all items of all ranks (at the granularity of
+        16 slots), with any item size mix the taper produces;
+      * every cell of every partial row has exactly one writer;
+      * pushing "how many bodies did this cell's writer sum over" through the row tables, the reduce-scatter chunk
+        layout and the own-triangle addend gives every slot exactly `slots` interactions — i.e. the data flow of a
+        step, launch by launch, loses and duplicates nothing."""
+    slice_ = mh.slice_slots(n, world)
+    slots, tb = slice_ * world, slice_ // 1024
+    G = 16
+    count = np.zeros((slots // G, slots // G), np.int32)
+    recv = np.zeros((world, slice_), np.int64)     # what the reduce-scatter delivers: sum over ranks of their chunk for a slice
+    own = np.zeros((world, slice_), np.int64)      # own-triangle row sums (exchange pipeline) / everything (one GPU)
+    for r in range(world):
+        items, rows, fm, ft = mh.schedule_layout(n, world, r, split, waves, taper, 50, exchange)
+        assert len(items) > 0
+        sets = {0: np.zeros(fm, np.int32), 1: np.zeros(ft, np.int32)}      # writers per cell
+        vals = {0: np.zeros(fm, np.int64), 1: np.zeros(ft, np.int64)}      # bodies summed into the cell
+        launches = items[:, 7]
+        assert (np.diff(launches) >= 0).all()                              # launch order
+        for i0, ln, J, flags, st, ioff, joff, launch in items:
+            assert ln % (4 * waves) == 0 and ln >= 16 * waves and i0 % (4 * waves) == 0 and i0 // 1024 == (i0 + ln - 1) // 1024
+            diag = bool(flags & 1)
+            assert diag == (i0 // 1024 == J)
+            if exchange or world > 1:
+                assert st == (1 if launch < 2 else 0)
+                assert (i0 // 1024) // tb == r                              # a rank walks its own bodies on the i side
+            count[i0 // G:(i0 + ln) // G, J * 1024 // G:(J + 1) * 1024 // G] += 1
+            sets[st][ioff:ioff + ln] += 1
+            vals[st][ioff:ioff + ln] += 1024
+            if not diag:
+                count[J * 1024 // G:(J + 1) * 1024 // G, i0 // G:(i0 + ln) // G] += 1
+                sets[st][joff:joff + 1024] += 1
+                vals[st][joff:joff + 1024] += ln
+        for st in (0, 1):
+            assert (sets[st] == 1).all(), (r, st, np.unique(sets[st]))
+        seen = {0: np.zeros(fm, bool), 1: np.zeros(ft, bool)}
+        for st, out_slice, out_block, base_i, ni, base_j, nj in rows:
+            assert not seen[st][base_j:base_j + nj * 1024].any() and not seen[st][base_i:base_i + ni * 1024].any()
+            seen[st][base_j:base_j + nj * 1024] = True
+            seen[st][base_i:base_i + ni * 1024] = True
+            tot = vals[st][base_j:base_j + nj * 1024].reshape(nj, 1024).sum(0) + vals[st][base_i:base_i + ni * 1024].reshape(ni, 1024).sum(0)
+            if exchange or world > 1:
+                if st == 1:
+                    assert out_slice == 0
+                    own[r, out_block * 1024:(out_block + 1) * 1024] += tot
+                else:
+                    recv[out_slice, out_block * 1024:(out_block + 1) * 1024] += tot
+            else:
+                own[0, out_block * 1024:(out_block + 1) * 1024] += tot
+        for st in (0, 1):
+            assert seen[st].all()                                          # the tables account for every row
+    assert (count == 1).all(), np.unique(count)
+    assert ((own + recv) == slots).all()
+
+
+def test_layout_query_rejects_bad_arguments(mh):
+    lib = mh.lib()
+    cnt = C.c_ulong()
+    bad = [(1000, 0, 0, 1, 4, 0, 50, 0), (1000, 2, 2, 1, 4, 0, 50, 0), (1000, 1, 0, 3, 4, 0, 50, 0), (1000, 1, 0, 1, 5, 0, 50, 0),
+           (1000, 1, 0, 1, 4, 101, 50, 0), (1000, 1, 0, 16, 8, 0, 50, 0), (1000, 65, 0, 1, 4, 0, 50, 0)]
+    for a in bad:
+        assert lib.murbhip_schedule_layout(*a, None, 0, C.byref(cnt), None, 0, C.byref(cnt), None, None) == -2000, a
+
+
 def test_simulation_history_csv(mh, tmp_path):
     """SimulationHistory<double>::saveMetricsToCSV: the reference's column names and max_digits10
     precision (SimulationHistory.cpp:103-121), so the doubles survive the round trip exactly."""

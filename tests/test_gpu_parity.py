@@ -286,6 +286,69 @@ def test_sharded_benchmark_size(gpu, O, shards):
             np.testing.assert_allclose(s2[k], s1[k], rtol=TOL_POS, atol=1.0)
 
 
+def test_sharded_config4_one_million_over_8_shards(gpu, O):
+    """BASELINE.json configs[4]: N = 1 000 000 cut over 8 shards (here time-sharing one GPU, peer-copy exchange), the
+    library's own choice of schedule: spot check against the fp64 truth, momentum balance, per-shard footprint, and two
+    steps against the single-GPU run."""
+    n, shards = 1000000, 8
+    s = O.init_bodies(n, "galaxy")
+    idx = np.random.default_rng(12).choice(n, 1024, replace=False)
+    truth = O.accel_f64_subset(s, idx, SOFT)
+    with gpu.Simulation(n, soft=SOFT, devices=[0] * shards) as many:
+        assert many.info("variant") == 8 and many.info("world") == shards
+        many.upload(s)
+        many.compute_acc()
+        many.sync()
+        a = many.acc()
+        assert O.rel_err(tuple(c[idx] for c in a), truth).max() <= TOL_F64_MAX
+        m = s["m"].astype(np.float64)
+        tot = np.array([(m * c.astype(np.float64)).sum() for c in a])
+        scale = np.array([(m * np.abs(c.astype(np.float64))).sum() for c in a])
+        assert (np.abs(tot) / scale).max() <= 1e-6
+        many.steps(DT, 2)
+        many.sync()
+        s2 = many.state()
+        per_shard = many.info("device_bytes") / shards
+    with gpu.Simulation(n, soft=SOFT) as one:
+        one.upload(s)
+        one.steps(DT, 2)
+        one.sync()
+        s1 = one.state()
+        single = one.info("device_bytes")
+    for k in ("qx", "qy", "qz"):
+        np.testing.assert_allclose(s2[k], s1[k], rtol=TOL_POS, atol=1.0)
+    for k in ("vx", "vy", "vz"):
+        np.testing.assert_allclose(s2[k], s1[k], rtol=1e-5, atol=1e-5)
+    # a rank only holds the partial-sum rows it writes: well under a third of the single-GPU footprint
+    assert per_shard < 0.3 * single, (per_shard, single)
+
+
+def test_cu_reserve_changes_nothing_but_the_streams(gpu, O):
+    """"cu_reserve": the compute streams are re-created with a CU mask (CUs left to the exchange stream's kernels);
+    results stay bit-identical, the option can be switched back and forth mid-run."""
+    n = 20000
+    s = O.init_bodies(n, "galaxy")
+    with gpu.Simulation(n, soft=SOFT) as a, gpu.Simulation(n, soft=SOFT, devices=[0, 0]) as b, gpu.Simulation(n, soft=SOFT) as ref:
+        for sim in (a, b, ref):
+            sim.upload(s)
+        a.set_option("cu_reserve", 8)
+        b.set_option("cu_reserve", 16)
+        assert a.info("cu_reserve") == 8 and b.info("cu_reserve") == 16
+        for sim in (a, b, ref):
+            sim.steps(DT, 2)
+        a.set_option("cu_reserve", 0)
+        for sim in (a, b, ref):
+            sim.steps(DT, 1)
+            sim.sync()
+        sa, sb, sr = a.state(), b.state(), ref.state()
+        for k in ("qx", "qy", "qz", "vx", "vy", "vz"):
+            assert np.array_equal(bits(sa[k]), bits(sr[k])), k
+        for k in ("qx", "qy", "qz"):
+            np.testing.assert_allclose(sb[k], sr[k], rtol=TOL_POS, atol=1.0)
+        with pytest.raises(gpu.MurbHipError):
+            a.set_option("cu_reserve", 100000)
+
+
 def test_rank_mode_single_rank(gpu, O):
     """One process per GPU entry point with world = 1 (RCCL not needed, same results)."""
     n = 2048
@@ -547,6 +610,20 @@ def test_bench_contract(gpu):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and d["gpu_over_cpu"] > 1
+    assert cb["cpu"]["model"] and cb["cpu"]["logical_cpus"] >= cb["cores"] >= 1
+    # the workload string names the size that ran and the BASELINE.json config it is
+    assert "N=30000" in d["config"]["workload"] and "configs[1]" in d["config"]["workload"]
+    # peak from the device's properties; algorithmic vs executed flops kept apart
+    assert abs(roof["peak"] - d["device"]["cu_count"] * 256 * d["device"]["clock_mhz"] * 1e-6) < 1e-6
+    assert abs(roof["frac_executed"] - roof["frac"] * roof["executed_flop_per_interaction"] / 20.0) < 1e-9
+    # the parity gate at N = 30 000 after 1 and 5 steps, vs cpu+optim and vs fp64, max and rms
+    gate = d["parity_gate_n30000"]
+    assert gate["pass"] is True and gate["n_bodies"] == 30000 and gate["steps"] == [1, 5]
+    for k in (1, 5):
+        e = gate[f"after_{k}_steps"]
+        assert e["acc_vs_cpu_optim"]["max"] <= 3e-5 and e["acc_vs_cpu_optim"]["rms"] <= 1e-5
+        assert e["acc_vs_fp64"]["max"] <= 2e-6 and e["pos_vs_cpu_optim"]["max"] <= 2e-6 and e["pos_vs_fp64"]["max"] <= 2e-6
+        assert e["acc_vs_fp64"]["max"] <= e["cpu_optim_acc_vs_fp64"]["max"]   # closer to the truth than the reference's CPU path
 
 
 def test_bench_under_torchrun_one_rank(gpu):

@@ -22,10 +22,12 @@ WORKER = os.path.join(ROOT, "tests", "_rank_worker.py")
 SOFT, DT = np.float32(2e8), np.float32(3600.0)
 
 
-def run_ranks(tmp_path, world, n, steps, variant, overlap=1, jsplit=0, integrator=0):
+def run_ranks(tmp_path, world, n, steps, variant, overlap=1, jsplit=0, integrator=0, mode="async"):
+    """mode: "async" = the stand-in only enqueues its copies and host functions on the stream it is given (what real
+    RCCL does; a missing cross-stream wait in the library then shows as a wrong result), "sync" = it drains the stream."""
     if not os.path.exists(MOCK):   # normally built by __graft_entry__.build()
         subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "helpers")], check=True, timeout=600)
-    env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK)
+    env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK, MURB_MOCK_MODE=mode)
     # the unique id comes from the same library the ranks will bind: ask a throw-away process for it
     uid = subprocess.run([sys.executable, "-c",
                           f"import sys; sys.path.insert(0, {os.path.join(ROOT, 'nbody-eurohpc_amd')!r}); import murbhip; "
@@ -55,18 +57,21 @@ def run_ranks(tmp_path, world, n, steps, variant, overlap=1, jsplit=0, integrato
     return results
 
 
-@pytest.mark.parametrize("world,n,variant,overlap,jsplit", [
-    (2, 9000, 1, 1, 0),      # one-sided kernel, all-gather only
-    (2, 9000, 8, 1, 0),      # half-ring schedule, even world (shared slice pair)
-    (3, 9001, 8, 1, 2),      # odd world, bodies not divisible by it (ranks own 3001 / 3000 / 3000)
-    (4, 10003, 1, 0, 0),     # one-sided, ragged partition
-    (4, 20000, 8, 0, 0),     # no overlap
-    (4, 20000, 8, 1, 4),
-    (3, 12000, 8, 2, 1),     # overlap mode 2 (at most 4 ranks here: the GPU box allows 6 processes on the card, pytest is one)
+@pytest.mark.parametrize("world,n,variant,overlap,jsplit,mode", [
+    (2, 9000, 1, 1, 0, "async"),      # one-sided kernel, all-gather only
+    (2, 9000, 8, 1, 0, "async"),      # half-ring schedule, even world (shared slice pair)
+    (3, 9001, 8, 1, 2, "async"),      # odd world, bodies not divisible by it (ranks own 3001 / 3000 / 3000)
+    (4, 10003, 1, 0, 0, "async"),     # one-sided, ragged partition
+    (4, 20000, 8, 0, 0, "async"),     # no overlap
+    (4, 20000, 8, 1, 4, "async"),
+    (3, 12000, 8, 2, 1, "async"),     # overlap mode 2 (at most 4 ranks here: the GPU box allows 6 processes on the card, pytest is one)
+    (4, 40000, 8, 1, 0, "async"),     # longer force launches: the collectives really do run beside them
+    (2, 9000, 8, 1, 0, "sync"),       # the draining stand-in of round 1, for comparison
+    (4, 20000, 8, 1, 4, "sync"),
 ])
-def test_ranks_match_single_gpu(gpu, O, tmp_path, world, n, variant, overlap, jsplit):
-    steps = 3
-    ranks = run_ranks(tmp_path, world, n, steps, variant, overlap, jsplit)
+def test_ranks_match_single_gpu(gpu, O, tmp_path, world, n, variant, overlap, jsplit, mode):
+    steps = 3 if n < 40000 else 6
+    ranks = run_ranks(tmp_path, world, n, steps, variant, overlap, jsplit, mode=mode)
     s = O.init_bodies(n, "galaxy")
     with gpu.Simulation(n, soft=SOFT) as one:
         one.upload(s)
@@ -142,6 +147,28 @@ def test_bench_py_with_several_ranks(gpu, world, n):
     assert chk["positions_identical_on_all_ranks"] and chk["finite"] and chk["max_position_diff_rel"] < 1e-5, chk
     assert "cpu_baseline" not in d      # rank 0 at N = 1 only
     assert d["tuned"]["tri_first_pct"] in (0, 25, 50, 75, 100) and len(d["tuned"]["ms_per_step_by_candidate"]) == 5
+    assert d["tuned"]["cu_reserve"] in (0, 8, 16) and len(d["tuned"]["ms_per_step_by_cu_reserve"]) == 3
+
+
+def test_bench_py_launches_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run around it: the script must start the launcher itself (as a
+    child process, before touching the GPU) and relay the one JSON line — the other launch convention a driver may use."""
+    import json
+    if not os.path.exists(MOCK):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "helpers")], check=True, timeout=600)
+    env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK, MURB_BENCH_BACKEND="gloo", MURB_BENCH_SHARE_GPU="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bodies", "40000", "--steps", "6",
+                        "--warmup", "1", "--cu-reserve", "8"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["tuned"]["cu_reserve"] == 8
+    chk = d["rank_mode_check"]
+    assert chk["positions_identical_on_all_ranks"] and chk["finite"] and chk["max_position_diff_rel"] < 1e-5, chk
 
 
 @pytest.mark.parametrize("shards,n,variant,overlap", [(2, 9000, 8, 1), (3, 9001, 8, 0), (4, 20000, 8, 1), (3, 9000, 1, 1)])
