@@ -317,8 +317,9 @@ def test_sharded_config4_one_million_over_8_shards(gpu, O):
         single = one.info("device_bytes")
     for k in ("qx", "qy", "qz"):
         np.testing.assert_allclose(s2[k], s1[k], rtol=TOL_POS, atol=1.0)
+    vscale = max(np.abs(s1[k]).max() for k in ("vx", "vy", "vz"))
     for k in ("vx", "vy", "vz"):
-        np.testing.assert_allclose(s2[k], s1[k], rtol=1e-5, atol=1e-5)
+        assert np.abs(s2[k] - s1[k]).max() <= 2e-5 * vscale, k
     # a rank only holds the partial-sum rows it writes: well under a third of the single-GPU footprint
     assert per_shard < 0.3 * single, (per_shard, single)
 
