@@ -76,8 +76,8 @@ int murbhip_schedule_items(unsigned long n, int world, int rank, int split, int*
 
 /* Host only: the same work list as the pair-symmetric kernel consumes it, with the layout of its partial sums —
  * what murbhip_step builds for (n, world, rank) under the given plan (`split` i-side sub-blocks per block, `waves` 4 or 8
- * per workgroup, `taper_pct` % of each launch cut into finer items, `tri_first_pct` % of the own-slice triangle in its
- * first launch; exchange_mode != 0 or world > 1: the three-launch pipeline with separate rows for the own-slice
+ * per workgroup, `taper_pct` % of each launch cut into finer items (+ 256: diagonal blocks as triangular pieces,
+ * option "diag_tri"), `tri_first_pct` % of the own-slice triangle in its first launch; exchange_mode != 0 or world > 1: the three-launch pipeline with separate rows for the own-slice
  * triangle).  Per item 8 longs: first i slot, number of i bodies, j block, flags (bit 0 = diagonal), row set (0 main,
  * 1 own-slice triangle), float offset of its i-side output, of its j-side output, launch (0, 1, 2).  Per row-table
  * entry 7 longs: row set, destination slice chunk, block inside it, offset and count of its i rows, offset and count of
@@ -192,6 +192,11 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  *   "taper"          variant 8: percentage (0..100) of each launch's work whose items are cut finer (the last
  *                    taper % in halves, the last taper/2 % in quarters): a shorter drain phase at the end of a launch.
  *                    -1 (default) = the plan's own choice
+ *   "diag_tri"       variant 8: 1 = a diagonal block (i block = j block) is cut into pieces of 128 i bodies that only
+ *                    evaluate the j bodies from their own position on (36 instead of 64 units of work per diagonal
+ *                    block); 0 = the full square with the i side kept.  -1 (default) = the plan's own choice
+ *   "sym_red"        variant 8: how the i-side sums of a group are folded over the wave: 0 = in registers (permlane
+ *                    swaps + DPP), 1 = through LDS (fewer VALU instructions).  -1 (default) = the plan's own choice
  *   "sym_waves"      variant 8: waves per workgroup, 4 or 8; 0 = auto (8, with `split` 8, on one GPU below
  *                    45 000 bodies: a short launch drains faster; 4 otherwise)
  *   "xcd_order"      variant 8: 0 (default) = j-major item order (round-robin dispatch then gives XCD x the i

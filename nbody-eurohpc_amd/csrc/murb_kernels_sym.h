@@ -94,6 +94,21 @@ __device__ __forceinline__ float murb_reduce12(float (&v)[12], int lane)
     return z;
 }
 
+// Scalar helpers kept in inline asm: written in C, LLVM turns "uniform value AND uniform mask" into a vector select
+// (v_mov + v_cndmask per use), which costs VALU issue slots in the interaction loop.
+__device__ __forceinline__ float murb_masked(float v, unsigned mask)   // SGPR operands: one s_and_b32
+{
+    float out;
+    asm("s_and_b32 %0, %1, %2" : "=s"(out) : "s"(v), "s"(mask) : "scc");
+    return out;
+}
+__device__ __forceinline__ unsigned murb_ones_if_ge(int p, int threshold)   // all ones iff p >= threshold (SGPRs)
+{
+    unsigned out;
+    asm("s_sub_i32 %0, %1, %2\n\ts_ashr_i32 %0, %0, 31" : "=s"(out) : "s"(threshold), "s"(p + 1) : "scc");
+    return out;
+}
+
 // one i body against a j pair, both directions
 __device__ __forceinline__ void murb_interact_sym(const murb_f2 xj, const murb_f2 yj, const murb_f2 zj, const murb_f2 gj,
                                                   const float xi, const float yi, const float zi, const float gi,
@@ -138,70 +153,41 @@ __device__ __forceinline__ void murb_interact_sym_phi(const murb_f2 xj, const mu
     phi_j = __builtin_elementwise_fma(inv, (murb_f2)(gi), phi_j);
 }
 
-// grid.x = items; 64 * WAVES threads.  MINW = waves per SIMD the register allocator must allow.
-// WAVES = 4: one wave per SIMD and workgroup, four workgroups per CU.  WAVES = 8: two waves per SIMD and
-// workgroup, two workgroups per CU — an item takes half as long and a CU's last workgroup still has two
-// waves per SIMD to interleave (a lone wave reaches 61 % of the issue rate, tools/sym_stamps.hip), which
-// shortens the drain phase of short launches; per item it pays one more combine stage.
-// ILOAD = 1 (what the library launches): the i bodies come through scalar loads (s_load_dwordx4 from the
-// constant address space, 4 per group) instead of 4 vector loads + 16 v_readfirstlane: 16 VALU issue slots
-// less per group of 576, +2.1 % at N=200k and +2.7 % at 30k, bit-identical results (tools/sload_lab.hip).
-// ILOAD = 0 keeps the vector-load form for that comparison.
-// PHI = 1: the same sweep for the potential (murbhip_energy): phi instead of the three acceleration components,
-// written to plane 0 only (the cells of planes 1 and 2 keep whatever they held; their row sums are not used).
-template <int MINW, int WAVES = 4, int ILOAD = 0, int PHI = 0>
-__global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const MurbSymArgs a)
+// The walk of one wave over its share of an item's i range: groups of R bodies (coordinates and G*m in SGPRs) against
+// the j block in LDS, i-side sums reduced and stored per group, j-side sums left in the caller's registers.
+// DYN = 0: every step applies both sides (items off the diagonal; also the plain form of a diagonal item, whose j side
+// is then simply not written).  DYN = 1: a diagonal item in its triangular form — the i range covers the j bodies of
+// steps [p_first, p_sym): steps before p_first are skipped (those pairs belong to the items of the earlier i ranges,
+// which apply both sides), steps in [p_first, p_sym) keep the i side only (their j bodies include the i bodies
+// themselves), steps from p_sym on apply both sides.
+template <int WAVES, int ILOAD, int PHI, int RED, int DYN>
+__device__ __forceinline__ void murb_sym_walk(const MurbSymArgs& a, const float4* tileA, const float4* tileB, float* stage,
+                                              const int lane, const int wave, const int groups_per_wave,
+                                              const unsigned int i_block_slot, const unsigned long out_off, const int p_first,
+                                              const int p_sym, murb_f2 (&ajx)[MURB_SYM_STEPS], murb_f2 (&ajy)[MURB_SYM_STEPS],
+                                              murb_f2 (&ajz)[MURB_SYM_STEPS])
 {
     constexpr int R = MURB_SYM_R;
-    constexpr int THREADS = 64 * WAVES;
-    __shared__ float4 tileA[MURB_SYM_PAIRS];                    // {x0,x1,y0,y1} of the J block
-    __shared__ float4 tileB[MURB_SYM_PAIRS];                    // {z0,z1,gm0,gm1}
-    __shared__ murb_f2 scratch[WAVES / 2][3][MURB_SYM_PAIRS];   // cross-wave combine of the j-side sums
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    // this workgroup's item from the host-built table (uniform address: scalar loads)
-    const MurbSymItem it = a.items[a.item_first + blockIdx.x];
-    const int J = __builtin_amdgcn_readfirstlane(it.J);
-    const int i_item_slot = __builtin_amdgcn_readfirstlane(it.i_slot0);
-    const int groups_per_wave = __builtin_amdgcn_readfirstlane(it.ngroups);
-    const bool diagonal = (__builtin_amdgcn_readfirstlane(it.flags) & 1) != 0;
     const float soft2 = a.soft2;
-#ifdef MURB_LAB_BEGIN     /* tools/sym_stamps.hip: per-workgroup time stamps (never defined in the product build) */
-    MURB_LAB_BEGIN();
-#endif
-
-    // stage the J block: 2 layout tiles, A records to tileA, B records to tileB
-    {
-        const float4* src = a.rec + (unsigned long)J * (MURB_SYM_BLOCK / MURB_TILE_BODIES) * MURB_TILE_F4;
-#pragma unroll
-        for (int k = threadIdx.x; k < 2 * MURB_TILE_F4; k += THREADS) {
-            const int tile = k / MURB_TILE_F4, in = k % MURB_TILE_F4;
-            const float4 v = src[k];
-            if (in < MURB_TILE_PAIRS) tileA[tile * MURB_TILE_PAIRS + in] = v;
-            else tileB[tile * MURB_TILE_PAIRS + in - MURB_TILE_PAIRS] = v;
-        }
-    }
-    __syncthreads();
-
-    murb_f2 ajx[MURB_SYM_STEPS], ajy[MURB_SYM_STEPS], ajz[MURB_SYM_STEPS];
-#pragma unroll
-    for (int p = 0; p < MURB_SYM_STEPS; ++p) { ajx[p] = (murb_f2)(0.f); ajy[p] = (murb_f2)(0.f); ajz[p] = (murb_f2)(0.f); }
-
-    const unsigned int i_block_slot = (unsigned int)i_item_slot;
-    // where this lane's i-side total goes: value idx(lane) = 3 * body + component (see murb_reduce12)
-    unsigned long out_off;
-    {
-        const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
-        const int idx = b2 ? 8 + 2 * b4 + b5 : 4 * b3 + 2 * b4 + b5;
-        const int r = idx / 3, c = idx - 3 * r;
-        out_off = (unsigned long)c * a.comp_stride + it.ioff + r;
-    }
+    const int stage_wr = (lane >> 4) * 20 + (lane & 15);
+    const int stage_rd = ((lane >> 2) < 12 ? (lane >> 2) : 11) * 80 + (lane & 3) * 20;
+    // RED = 1: four lanes per value add up its 64 staged entries
+    const auto team_sum = [&](int g_of) {
+        const float4* src = reinterpret_cast<const float4*>(stage + stage_rd);
+        const float4 t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3];
+        murb_f2 s2 = (murb_f2){t0.x, t0.y} + (murb_f2){t0.z, t0.w};
+        s2 += (murb_f2){t1.x, t1.y}; s2 += (murb_f2){t1.z, t1.w};
+        s2 += (murb_f2){t2.x, t2.y}; s2 += (murb_f2){t2.z, t2.w};
+        s2 += (murb_f2){t3.x, t3.y}; s2 += (murb_f2){t3.z, t3.w};
+        float z = s2.x + s2.y;
+        z += murb_dpp<0xB1>(z);                               // quad_perm [1,0,3,2]
+        z += murb_dpp<0x4E>(z);                               // quad_perm [2,3,0,1]
+        a.part[(unsigned long)out_off + g_of * R] = z;
+    };
 #pragma unroll 1
     for (int gk = 0; gk < groups_per_wave; ++gk) {
         asm volatile("" ::: "memory");   // keep the tile reads inside the loop: 64 VGPRs of hoisted j data spill
-        const int g = gk * WAVES + wave;                        // interleave the waves over the block
+        const int g = gk * WAVES + wave;                        // interleave the waves over the range
         const unsigned int i_slot = i_block_slot + g * R;       // wave-uniform
         float xi[R], yi[R], zi[R], gi[R];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -245,21 +231,26 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const 
 
 #pragma unroll
         for (int p = 0; p < MURB_SYM_STEPS; ++p) {
-            const float4 A = tileA[p * 64 + lane];
-            const float4 B = tileB[p * 64 + lane];
-            const murb_f2 xj = {A.x, A.y}, yj = {A.z, A.w}, zj = {B.x, B.y}, gj = {B.z, B.w};
+            if (DYN == 0 || p >= p_first) {   // wave-uniform
+                const float4 A = tileA[p * 64 + lane];
+                const float4 B = tileB[p * 64 + lane];
+                const murb_f2 xj = {A.x, A.y}, yj = {A.z, A.w}, zj = {B.x, B.y}, gj = {B.z, B.w};
+                // scalar mask: 0 where this step's j bodies include the i bodies themselves (their j side is dropped)
+                const unsigned both = DYN ? murb_ones_if_ge(p, p_sym) : ~0u;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if constexpr (PHI == 1)
-                    murb_interact_sym_phi(xj, yj, zj, gj, xi[r], yi[r], zi[r], gi[r], soft2, aix[r], ajx[p]);
-                else
-                    murb_interact_sym(xj, yj, zj, gj, xi[r], yi[r], zi[r], gi[r], soft2, aix[r], aiy[r], aiz[r], ajx[p],
-                                      ajy[p], ajz[p]);
+                for (int r = 0; r < R; ++r) {
+                    const float gie = DYN ? murb_masked(gi[r], both) : gi[r];
+                    if constexpr (PHI == 1)
+                        murb_interact_sym_phi(xj, yj, zj, gj, xi[r], yi[r], zi[r], gie, soft2, aix[r], ajx[p]);
+                    else
+                        murb_interact_sym(xj, yj, zj, gj, xi[r], yi[r], zi[r], gie, soft2, aix[r], aiy[r], aiz[r], ajx[p], ajy[p],
+                                          ajz[p]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);   // one step at a time: bounds the live temporaries
         }
 
-        // i side: 12 sums -> lanes, one float per (body, component) -> partial row J
+        // i side: 12 sums -> lanes, one float per (body, component) -> the item's i row
         float v[12];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -267,15 +258,98 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const 
             v[3 * r + 1] = aiy[r].x + aiy[r].y;
             v[3 * r + 2] = aiz[r].x + aiz[r].y;
         }
-        const float total = murb_reduce12(v, lane);
         // Every lane stores (no branch in the loop body: a conditional store here makes LLVM sink the
         // j-side FMAs into the loop latch and spill 32 x 8 registers).  Lanes that hold the same total
         // write the same value to the same address.
-        a.part[(unsigned long)out_off + g * R] = total;
+        if constexpr (RED == 0) {
+            a.part[(unsigned long)out_off + g * R] = murb_reduce12(v, lane);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) stage[k * 80 + stage_wr] = v[k];
+            team_sum(g);
+        }
     }
+}
 
-    // j side: fold the waves pairwise in a fixed order (WAVES = 4: 3+2 -> 1+0 -> 0), wave 0 writes partial row I
-    if (!diagonal) {
+// grid.x = items; 64 * WAVES threads.  MINW = waves per SIMD the register allocator must allow.
+// WAVES = 4: one wave per SIMD and workgroup, four workgroups per CU.  WAVES = 8: two waves per SIMD and
+// workgroup, two workgroups per CU — an item takes half as long and a CU's last workgroup still has two
+// waves per SIMD to interleave (a lone wave reaches 61 % of the issue rate, tools/sym_stamps.hip), which
+// shortens the drain phase of short launches; per item it pays one more combine stage.
+// ILOAD = 1 (what the library launches): the i bodies come through scalar loads (s_load_dwordx4 from the
+// constant address space, 4 per group) instead of 4 vector loads + 16 v_readfirstlane: 16 VALU issue slots
+// less per group of 576, +2.1 % at N=200k and +2.7 % at 30k, bit-identical results.  ILOAD = 0 keeps the vector-load form.
+// PHI = 1: the same sweep for the potential (murbhip_energy): phi instead of the three acceleration components,
+// written to component 0 only (the cells of components 1 and 2 keep whatever they held; their row sums are not used).
+// RED = 0: the 12 i-side sums of a group are folded in registers (murb_reduce12: 39 VALU instructions).  RED = 1: through
+// LDS — each lane adds the two halves of its 12 sums and stores them (12 ds_write_b32 into a per-wave area aliased with
+// the end-of-item combine scratch, rows padded so that the reads are conflict-free), then teams of four lanes sum one
+// value's 64 entries (4 ds_read_b128 and 7 packed adds per lane, one add, two DPP adds): 22 VALU instructions per group.
+// (Taking the team sums one group later, in the middle of the next group's sweep, to cover the LDS round trip, measured
+// 2 % SLOWER than RED = 1 at N = 200 000 and was dropped.)
+template <int MINW, int WAVES = 4, int ILOAD = 0, int PHI = 0, int RED = 0>
+__global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const MurbSymArgs a)
+{
+    constexpr int R = MURB_SYM_R;
+    constexpr int THREADS = 64 * WAVES;
+    __shared__ float4 tileA[MURB_SYM_PAIRS];                    // {x0,x1,y0,y1} of the J block
+    __shared__ float4 tileB[MURB_SYM_PAIRS];                    // {z0,z1,gm0,gm1}
+    __shared__ murb_f2 scratch[WAVES / 2][3][MURB_SYM_PAIRS];   // cross-wave combine of the j-side sums
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // this workgroup's item from the host-built table (uniform address: scalar loads)
+    const MurbSymItem it = a.items[a.item_first + blockIdx.x];
+    const int J = __builtin_amdgcn_readfirstlane(it.J);
+    const int i_item_slot = __builtin_amdgcn_readfirstlane(it.i_slot0);
+    const int groups_per_wave = __builtin_amdgcn_readfirstlane(it.ngroups);
+    const int flags = __builtin_amdgcn_readfirstlane(it.flags);
+    const bool no_j_side = (flags & 1) != 0;            // nothing to write on the j side
+    const bool triangular = (flags & 2) != 0;           // diagonal item in its triangular form (murb_sym_walk, DYN = 1)
+    const int p_first = (flags >> 8) & 15, p_sym = (flags >> 12) & 15;
+#ifdef MURB_LAB_BEGIN     /* tools/sym_stamps.hip: per-workgroup time stamps (never defined in the product build) */
+    MURB_LAB_BEGIN();
+#endif
+
+    // stage the J block: 2 layout tiles, A records to tileA, B records to tileB
+    {
+        const float4* src = a.rec + (unsigned long)J * (MURB_SYM_BLOCK / MURB_TILE_BODIES) * MURB_TILE_F4;
+#pragma unroll
+        for (int k = threadIdx.x; k < 2 * MURB_TILE_F4; k += THREADS) {
+            const int tile = k / MURB_TILE_F4, in = k % MURB_TILE_F4;
+            const float4 v = src[k];
+            if (in < MURB_TILE_PAIRS) tileA[tile * MURB_TILE_PAIRS + in] = v;
+            else tileB[tile * MURB_TILE_PAIRS + in - MURB_TILE_PAIRS] = v;
+        }
+    }
+    __syncthreads();
+
+    murb_f2 ajx[MURB_SYM_STEPS], ajy[MURB_SYM_STEPS], ajz[MURB_SYM_STEPS];
+#pragma unroll
+    for (int p = 0; p < MURB_SYM_STEPS; ++p) { ajx[p] = (murb_f2)(0.f); ajy[p] = (murb_f2)(0.f); ajz[p] = (murb_f2)(0.f); }
+
+    // where this lane's i-side total goes: value idx(lane) = 3 * body + component (see murb_reduce12)
+    unsigned long out_off;
+    {
+        const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
+        int idx = b2 ? 8 + 2 * b4 + b5 : 4 * b3 + 2 * b4 + b5;
+        if constexpr (RED != 0) idx = (lane >> 2) < 12 ? (lane >> 2) : 11;   // team of four lanes per value; lanes 48-63 repeat value 11
+        const int r = idx / 3, c = idx - 3 * r;
+        out_off = (unsigned long)c * a.comp_stride + it.ioff + r;
+    }
+    // RED = 1: this wave's staging area (12 rows of 64 floats, a quarter row padded to 20 floats, a row to 80)
+    float* const stage = reinterpret_cast<float*>(&scratch[0][0][0]) + wave * (12 * 80);
+    if (triangular)
+        murb_sym_walk<WAVES, ILOAD, PHI, RED, 1>(a, tileA, tileB, stage, lane, wave, groups_per_wave, (unsigned int)i_item_slot, out_off,
+                                                 p_first, p_sym, ajx, ajy, ajz);
+    else
+        murb_sym_walk<WAVES, ILOAD, PHI, RED, 0>(a, tileA, tileB, stage, lane, wave, groups_per_wave, (unsigned int)i_item_slot, out_off,
+                                                 0, 0, ajx, ajy, ajz);
+
+    // j side: fold the waves pairwise in a fixed order (WAVES = 4: 3+2 -> 1+0 -> 0), wave 0 writes the item's j row
+    if (!no_j_side) {
+        if constexpr (RED != 0) __syncthreads();   // the scratch doubles as the waves' staging areas
 #pragma unroll
         for (int half = WAVES / 2; half >= 1; half >>= 1) {
             if (wave >= half && wave < 2 * half) {
@@ -366,15 +440,18 @@ __device__ __forceinline__ bool murb_sym_rowsum_slot(const float* part, unsigned
     return true;
 }
 
-// grid.x = 16 workgroups per table entry (64 slots each)
+// grid.x = 16 workgroups per table entry (64 slots each).  The table is walked from its END: under the j-major item
+// order the last blocks own the most rows (the tail of a launch is cut into finer items, each with a j row of its own), and
+// their workgroups should start first.
 __global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_kernel(const float* part, unsigned long comp_stride,
                                                                               const MurbSymBlockRows* rows, float* out,
                                                                               unsigned int out_slice_slots)
 {
     __shared__ double red[MURB_ROWSUM_GROUPS - 1][3][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const MurbSymBlockRows br = rows[blockIdx.x / (MURB_SYM_BLOCK / 64)];
-    const unsigned int in_block = (blockIdx.x % (MURB_SYM_BLOCK / 64)) * 64 + lane;
+    const unsigned int wg = gridDim.x - 1 - blockIdx.x;
+    const MurbSymBlockRows br = rows[wg / (MURB_SYM_BLOCK / 64)];
+    const unsigned int in_block = (wg % (MURB_SYM_BLOCK / 64)) * 64 + lane;
     double total[3];
     if (!murb_sym_rowsum_slot(part, comp_stride, br, in_block, g, lane, red, total)) return;
 #pragma unroll
@@ -394,8 +471,9 @@ __global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_integrate
 #pragma clang fp contract(off)
     __shared__ double red[MURB_ROWSUM_GROUPS - 1][3][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const unsigned int s = blockIdx.x * 64 + lane;
-    const MurbSymBlockRows br = rows[blockIdx.x / (MURB_SYM_BLOCK / 64)];
+    const unsigned int wg = gridDim.x - 1 - blockIdx.x;   // last blocks first: they own the most rows
+    const unsigned int s = wg * 64 + lane;
+    const MurbSymBlockRows br = rows[wg / (MURB_SYM_BLOCK / 64)];
     double total[3];
     if (!murb_sym_rowsum_slot(part, comp_stride, br, s % MURB_SYM_BLOCK, g, lane, red, total)) return;
     const float ax = (float)total[0], ay = (float)total[1], az = (float)total[2];

@@ -92,19 +92,29 @@ void sym_schedule_items(int world, int rank, int tb, int split, std::vector<int>
 }
 
 // A piece of work for one workgroup of the pair-symmetric kernel: the i bodies [i_slot0, i_slot0 + len) against j
-// block J; `diag` = the i range lies inside block J (full square evaluated, i side kept).
+// block J.  flags (= MurbSymItem::flags): bit 0 = nothing is written on the j side; bit 1 = diagonal item in its
+// triangular form, with bits 8-11 = first step evaluated, bits 12-15 = first step that applies both sides (a step = the
+// 128 bodies a lane's p-th pair vector covers).
 struct SymPiece {
-    int i_slot0, len, J;
-    bool diag;
+    int i_slot0, len, J, flags;
+    bool diag() const { return i_slot0 / MURB_SLICE_ALIGN == J; }
+    bool j_side() const { return (flags & 1) == 0; }
 };
+constexpr int kSymStepBodies = 128;
 
-// (i sub-block, j block) pairs -> pieces.  `taper_pct` > 0 cuts the i side of the LAST items of each launch finer:
-// the last taper_pct % of a launch's work in halves, the last taper_pct / 2 % in quarters (never below `min_len`
-// bodies).  The hardware deals workgroups in table order, so the drain phase of a launch — when the last workgroups
-// of each CU run alone at 61 % of the issue rate — then consists of short items.  `launch_ends` lists
-// the item indices (of `flat`) at which a launch ends (the last one = number of items).
-inline void sym_pieces(const std::vector<int>& flat, int split, int taper_pct, int min_len, const std::vector<size_t>& launch_ends,
-                       std::vector<SymPiece>& out, std::vector<size_t>& piece_launch_ends)
+// (i sub-block, j block) pairs -> pieces.
+//   taper_pct > 0 cuts the i side of the LAST items of each launch finer, geometrically: the last taper_pct % of a
+//     launch's work in halves, the last taper_pct / 2 % in quarters, the last taper_pct / 4 % in eighths, ... (never
+//     below `min_len` bodies).  The hardware deals workgroups in table order and a CU works through ~75 items of 0.33 ms
+//     four at a time (N = 200 000): at the end of a launch the CUs run dry up to one item time apart, and the last
+//     workgroups of a CU run alone at 61 % of the issue rate.  With the tail cut fine both effects shrink
+//     with the item length.  `launch_ends` lists the item indices (of `flat`) at which a launch ends (the last one =
+//     number of items).
+//   diag_tri: a diagonal block (i block == j block) is cut into pieces of at most 128 bodies, each evaluating only the
+//     j steps from its own on: its own step one-sided, the later ones both ways — 36 instead of 64 step units per
+//     diagonal block (plain form: the full square, i side kept).
+inline void sym_pieces(const std::vector<int>& flat, int split, int taper_pct, int min_len, bool diag_tri,
+                       const std::vector<size_t>& launch_ends, std::vector<SymPiece>& out, std::vector<size_t>& piece_launch_ends)
 {
     const int len = MURB_SLICE_ALIGN / split;
     out.clear();
@@ -114,15 +124,24 @@ inline void sym_pieces(const std::vector<int>& flat, int split, int taper_pct, i
         const double total = (double)(end - first);
         for (size_t k = first; k < end; ++k) {
             const int isub = flat[2 * k], J = flat[2 * k + 1];
+            const bool diag = isub / split == J;
             const double before = (double)(k - first) / (total > 0 ? total : 1.0);
             int div = 1;
             if (taper_pct > 0) {
-                if (before >= 1.0 - taper_pct / 200.0) div = 4;
-                else if (before >= 1.0 - taper_pct / 100.0) div = 2;
-                while (div > 1 && len / div < min_len) div /= 2;
+                const double left = 1.0 - before;   // share of the launch still to be dealt, this item included
+                for (double f = taper_pct / 100.0; left <= f && len / (2 * div) >= min_len; f *= 0.5) div *= 2;
             }
-            for (int q = 0; q < div; ++q)
-                out.push_back(SymPiece{isub * len + q * (len / div), len / div, J, isub / split == J});
+            if (diag && diag_tri)
+                while (len / div > kSymStepBodies && len / (2 * div) >= min_len) div *= 2;
+            for (int q = 0; q < div; ++q) {
+                SymPiece pc{isub * len + q * (len / div), len / div, J, diag ? 1 : 0};
+                if (diag && diag_tri && pc.len <= kSymStepBodies) {
+                    const int in_block = pc.i_slot0 % MURB_SLICE_ALIGN;
+                    const int a = in_block / kSymStepBodies, b = (in_block + pc.len + kSymStepBodies - 1) / kSymStepBodies;
+                    pc.flags = 2 | (a << 8) | (b << 12) | (b >= MURB_SLICE_ALIGN / kSymStepBodies ? 1 : 0);
+                }
+                out.push_back(pc);
+            }
         }
         piece_launch_ends.push_back(out.size());
         first = end;

@@ -76,7 +76,8 @@ struct Shard {
     // pair-symmetric kernel: item table and partial-row layouts (built by build_sym_schedule for one plan)
     MurbSymItem* sym_items = nullptr;
     int sym_items_own = 0, sym_items_total = 0;   // [0, own) = own-slice triangle, the rest need the gathered positions
-    int sym_split = 0, sym_waves = 0, sym_taper = -1;   // what the table was built for
+    int sym_split = 0, sym_waves = 0, sym_taper = -1, sym_diag_tri = -1;   // what the table was built for
+    int sym_red = 0;                              // i-side reduction of the plan (kernel template parameter)
     int sym_xcd_order = -1;                       // ... and the item order ("xcd_order")
     int sym_tri_first = -1, sym_overlap = -1;     // ... and the launch boundaries inside the own-slice triangle ("tri_first_pct", "overlap")
     int sym_t1 = 0;                               // items of the triangle's first launch (exchange pipeline, overlap 1)
@@ -125,6 +126,8 @@ struct murbhip_ctx {
     float lf_last_dt = 0.f;
     int force_exchange = 0;   // run the exchange even with one rank (self-test of the RCCL binding)
     int taper = -1;           // pair-symmetric kernel: % of each launch cut into finer items (-1 = the plan's default)
+    int diag_tri = -1;        // ... diagonal blocks as triangular pieces (-1 = the plan's default)
+    int sym_red = -1;         // ... i-side reduction in registers (0) or through LDS (1) (-1 = the plan's default)
     int cu_reserve = 0;       // CUs masked out of the compute streams (left free for the collectives' kernels)
     int solo_shard = -1;      // >= 0: only this shard computes (timing aid: one rank's isolated timeline
                               // when W shards share one GPU; results are then meaningless)
@@ -147,6 +150,8 @@ struct Plan {
     int split;                       // its i-side sub-blocks per block (1, 2, 4, 8, 16)
     int waves;                       // ... and its waves per workgroup (4 or 8)
     int taper;                       // ... and the share (%) of each launch whose items are cut finer ("taper")
+    bool diag_tri;                   // ... diagonal blocks in triangular pieces ("diag_tri")
+    int red;                         // ... i-side reduction: 0 registers, 1 LDS teams ("sym_red")
     MurbSchedule sched[2];           // [0] own slice (or everything), [1] the rest
 };
 
@@ -281,12 +286,24 @@ Plan make_plan(const murbhip_ctx* c)
         p.split = (c->jsplit == 1 || c->jsplit == 2 || c->jsplit == 4 || c->jsplit == 8 || c->jsplit == 16)
                       ? c->jsplit
                       : (items >= want ? 1 : (2 * items >= want ? 2 : 4));
-        // 8-wave workgroups (2 per SIMD, 2 workgroups per CU) drain faster at the end of a short launch
-        // (tools/waves_lab.hip: +4 % at N=30k with split 8, nothing from 60k up): used for one GPU below 45k
-        p.waves = (c->sym_waves == 4 || c->sym_waves == 8) ? c->sym_waves : ((c->world == 1 && c->n < 45000) ? 8 : 4);
-        if (c->jsplit == 0 && c->sym_waves == 0 && p.waves == 8) p.split = 8;
+        // One GPU below 45 000 bodies (BASELINE's N = 30 000: 465 block pairs for 1024 workgroup slots): 8-wave
+        // workgroups (2 per SIMD, 2 workgroups per CU: a CU's last workgroup still has two waves per SIMD to interleave),
+        // quarter-block items with the last 30 % of the launch cut finer, diagonal blocks as triangular pieces.
+        // tools/ab.py, interleaved, N = 30 000, wall per step: 8 waves / split 8 (round 1) 174.5 us, 8 / 4 / taper 30 /
+        // triangular diagonal 170.5, 8 / 2 / taper 60 171.4; 4 waves never better.
+        const bool small = c->world == 1 && c->n < 45000;
+        p.waves = (c->sym_waves == 4 || c->sym_waves == 8) ? c->sym_waves : (small ? 8 : 4);
+        if (c->jsplit == 0 && c->sym_waves == 0 && small) p.split = 4;
+        while (p.split > 1 && MURB_SYM_BLOCK / p.split < 16 * p.waves) p.split /= 2;   // an item is at least one group per wave
         while (p.split > 1 && !fits(p.split)) p.split /= 2;   // the rows of the split actually used must fit, too
-        p.taper = c->taper >= 0 ? c->taper : 0;
+        // the tail of a launch in finer items (murb_schedule.h): +1.2-1.4 % on the force launch at N = 200 000 with 5 %,
+        // nothing at 1M (the tail is 0.3 % of the launch there), and nothing on the wall clock of a rank of 8, whose three
+        // short launches gain what their row sums lose to the extra rows
+        p.taper = c->taper >= 0 ? c->taper : (c->world > 1 ? 0 : (small ? 30 : (c->n <= 600000 ? 5 : 0)));
+        p.diag_tri = c->diag_tri >= 0 ? c->diag_tri != 0 : small;
+        // i-side sums through LDS: 599 instead of 616 VALU instructions per group; +0.8-1.3 % at N = 200 000, +1.7 % for
+        // a rank of 8 (tools/ab.py)
+        p.red = c->sym_red >= 0 ? c->sym_red : 1;
         p.persistent = false;
         p.parts_local = p.parts_remote = 0;
         return p;
@@ -508,7 +525,7 @@ size_t layout_sym_set(const std::vector<SymPiece>& pieces, size_t first, size_t 
                       std::vector<MurbSymBlockRows>& table, OutOf out_of)
 {
     std::map<int, int> index;                       // global block -> table entry, ascending block order
-    for (size_t k = first; k < end; ++k) { index[pieces[k].i_slot0 / MURB_SYM_BLOCK] = 0; if (!pieces[k].diag) index[pieces[k].J] = 0; }
+    for (size_t k = first; k < end; ++k) { index[pieces[k].i_slot0 / MURB_SYM_BLOCK] = 0; if (pieces[k].j_side()) index[pieces[k].J] = 0; }
     table.assign(index.size(), MurbSymBlockRows{});
     { int e = 0; for (auto& kv : index) { kv.second = e; const auto o = out_of(kv.first); table[e].out_slice = o.first; table[e].out_block = o.second; ++e; } }
     std::vector<std::map<int, int>> irow(index.size());   // per block: j block -> i row
@@ -519,7 +536,7 @@ size_t layout_sym_set(const std::vector<SymPiece>& pieces, size_t first, size_t 
         auto f = irow[bi].find(pc.J);
         if (f == irow[bi].end()) f = irow[bi].emplace(pc.J, table[bi].ni++).first;
         item_irow[k - first] = f->second;
-        item_jrow[k - first] = pc.diag ? -1 : table[index[pc.J]].nj++;
+        item_jrow[k - first] = pc.j_side() ? table[index[pc.J]].nj++ : -1;
     }
     size_t floats = 0;
     for (MurbSymBlockRows& br : table) {
@@ -532,10 +549,10 @@ size_t layout_sym_set(const std::vector<SymPiece>& pieces, size_t first, size_t 
         it.i_slot0 = pc.i_slot0;
         it.ngroups = pc.len / (waves * MURB_SYM_R);
         it.J = pc.J;
-        it.flags = pc.diag ? 1 : 0;
+        it.flags = pc.flags;
         const MurbSymBlockRows& bi = table[index[pc.i_slot0 / MURB_SYM_BLOCK]];
         it.ioff = bi.base_i + (size_t)item_irow[k - first] * MURB_SYM_BLOCK + (size_t)(pc.i_slot0 % MURB_SYM_BLOCK);
-        it.joff = pc.diag ? 0 : table[index[pc.J]].base_j + (size_t)item_jrow[k - first] * MURB_SYM_BLOCK;
+        it.joff = pc.j_side() ? table[index[pc.J]].base_j + (size_t)item_jrow[k - first] * MURB_SYM_BLOCK : 0;
     }
     return floats;
 }
@@ -564,8 +581,8 @@ struct SymHostLayout {
     size_t floats_main = 0, floats_tri = 0;
 };
 
-void plan_sym_layout(int W, int r, int tb, int split, int waves, int taper, bool exchange_mode, int overlap, int tri_first_pct,
-                     bool xcd_order, SymHostLayout& L)
+void plan_sym_layout(int W, int r, int tb, int split, int waves, int taper, bool diag_tri, bool exchange_mode, int overlap,
+                     int tri_first_pct, bool xcd_order, SymHostLayout& L)
 {
     std::vector<int> flat;
     int own = 0;
@@ -583,7 +600,7 @@ void plan_sym_layout(int W, int r, int tb, int split, int waves, int taper, bool
     }
     std::vector<SymPiece> pieces;
     std::vector<size_t> piece_ends;
-    sym_pieces(flat, split, taper, 16 * waves, launch_ends, pieces, piece_ends);
+    sym_pieces(flat, split, taper, 16 * waves, diag_tri, launch_ends, pieces, piece_ends);
     size_t own_pieces = 0;   // pieces of the own-slice triangle = the leading ones whose j block is one of ours
     for (const SymPiece& pc : pieces) { if (pc.J / tb != r) break; ++own_pieces; }
     L.items.assign(pieces.size(), MurbSymItem{});
@@ -610,7 +627,8 @@ void plan_sym_layout(int W, int r, int tb, int split, int waves, int taper, bool
 int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
 {
     const bool exchange_mode = c->world > 1 || c->force_exchange;
-    if (sh.sym_items && sh.sym_split == p.split && sh.sym_waves == p.waves && sh.sym_taper == p.taper &&
+    sh.sym_red = p.red;
+    if (sh.sym_items && sh.sym_split == p.split && sh.sym_waves == p.waves && sh.sym_taper == p.taper && sh.sym_diag_tri == (int)p.diag_tri &&
         sh.sym_exchange_mode == exchange_mode && sh.sym_xcd_order == c->xcd_order &&
         (!exchange_mode || (sh.sym_tri_first == c->tri_first_pct && sh.sym_overlap == c->overlap)))
         return 0;
@@ -626,8 +644,8 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
     sh.sym_bytes = 0;
 
     SymHostLayout L;
-    plan_sym_layout(c->world, sh.rank, (int)(c->slice / MURB_SYM_BLOCK), p.split, p.waves, p.taper, exchange_mode, c->overlap,
-                    c->tri_first_pct, c->xcd_order != 0, L);
+    plan_sym_layout(c->world, sh.rank, (int)(c->slice / MURB_SYM_BLOCK), p.split, p.waves, p.taper, p.diag_tri, exchange_mode,
+                    c->overlap, c->tri_first_pct, c->xcd_order != 0, L);
     if (!exchange_mode && (int)L.table_main.size() != (int)(c->slots / MURB_SYM_BLOCK)) return MURBHIP_E_STATE;   // the fused row sum + integrate walks every block
     RC_TRY(upload_sym_set(sh, sh.sym_tri, L.table_tri, L.floats_tri));
     RC_TRY(upload_sym_set(sh, sh.sym_main, L.table_main, L.floats_main));
@@ -639,6 +657,7 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
     sh.sym_split = p.split;
     sh.sym_waves = p.waves;
     sh.sym_taper = p.taper;
+    sh.sym_diag_tri = (int)p.diag_tri;
     sh.sym_xcd_order = c->xcd_order;
     sh.sym_exchange_mode = exchange_mode;
     sh.sym_tri_first = c->tri_first_pct;
@@ -679,12 +698,15 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
     sa.soft2 = c->soft2;
     const bool timed = stream == sh.compute && !potential;   // the profiling events live on the main compute stream
     if (timed) RC_TRY(prof_begin(c, sh));
+    const dim3 grid((unsigned)count);
     if (sh.sym_waves == 8) {
-        if (potential) hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1, 1>), dim3((unsigned)count), dim3(512), 0, stream, sa);
-        else hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1>), dim3((unsigned)count), dim3(512), 0, stream, sa);
+        if (potential) hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1, 1>), grid, dim3(512), 0, stream, sa);
+        else if (sh.sym_red == 1) hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1, 0, 1>), grid, dim3(512), 0, stream, sa);
+        else hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1>), grid, dim3(512), 0, stream, sa);
     } else {
-        if (potential) hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1, 1>), dim3((unsigned)count), dim3(256), 0, stream, sa);
-        else hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1>), dim3((unsigned)count), dim3(256), 0, stream, sa);
+        if (potential) hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1, 1>), grid, dim3(256), 0, stream, sa);
+        else if (sh.sym_red == 1) hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1, 0, 1>), grid, dim3(256), 0, stream, sa);
+        else hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1>), grid, dim3(256), 0, stream, sa);
     }
     RC_TRY(hip_rc(hipGetLastError()));
     if (timed) RC_TRY(prof_end(c, sh));
@@ -1039,11 +1061,12 @@ int murbhip_schedule_layout(unsigned long n, int world, int rank, int split, int
 {
     if (world < 1 || world > MURB_SYM_MAX_RANKS || rank < 0 || rank >= world || !item_count || !row_count) return MURBHIP_E_INVALID;
     if (split != 1 && split != 2 && split != 4 && split != 8 && split != 16) return MURBHIP_E_INVALID;
-    if ((waves != 4 && waves != 8) || taper_pct < 0 || taper_pct > 100 || tri_first_pct < 0 || tri_first_pct > 100) return MURBHIP_E_INVALID;
+    if ((waves != 4 && waves != 8) || taper_pct < 0 || (taper_pct & 0xff) > 100 || taper_pct > 0x1ff || tri_first_pct < 0 || tri_first_pct > 100)
+        return MURBHIP_E_INVALID;
     if (MURB_SYM_BLOCK / split < 16 * waves) return MURBHIP_E_INVALID;
     SymHostLayout L;
-    plan_sym_layout(world, rank, (int)(slice_slots(n, world) / MURB_SYM_BLOCK), split, waves, taper_pct, exchange_mode != 0 || world > 1, 1,
-                    tri_first_pct, false, L);
+    plan_sym_layout(world, rank, (int)(slice_slots(n, world) / MURB_SYM_BLOCK), split, waves, taper_pct & 0xff, (taper_pct & 0x100) != 0,
+                    exchange_mode != 0 || world > 1, 1, tri_first_pct, false, L);
     *item_count = L.items.size();
     *row_count = L.table_main.size() + L.table_tri.size();
     if (floats_main) *floats_main = L.floats_main;
@@ -1454,7 +1477,8 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     else if (k == "xcd_order") c->xcd_order = value ? 1 : 0;
     else if (k == "tri_first_pct") { if (value < 0 || value > 100) return MURBHIP_E_INVALID; c->tri_first_pct = (int)value; }
     else if (k == "taper") { if (value < -1 || value > 100) return MURBHIP_E_INVALID; c->taper = (int)value; }
-    else if (k == "taper") { if (value < -1 || value > 100) return MURBHIP_E_INVALID; c->taper = (int)value; }
+    else if (k == "diag_tri") { if (value < -1 || value > 1) return MURBHIP_E_INVALID; c->diag_tri = (int)value; }
+    else if (k == "sym_red") { if (value < -1 || value > 1) return MURBHIP_E_INVALID; c->sym_red = (int)value; }
     else if (k == "sym_waves") { if (value != 0 && value != 4 && value != 8) return MURBHIP_E_INVALID; c->sym_waves = (int)value; }
     else if (k == "overlap") { if (value < 0 || value > 2) return MURBHIP_E_INVALID; c->overlap = (int)value; }
     else if (k == "integrator") {

@@ -171,13 +171,14 @@ def test_half_ring_schedule_covers_every_pair_once(mh, n, world, split):
         assert max(counts) - min(counts) <= split * tb, counts     # balanced up to one block row
 
 
+@pytest.mark.parametrize("diag_tri", [False, True])
 @pytest.mark.parametrize("n,world,split,waves,taper,exchange", [
     (5000, 1, 1, 4, 0, False), (5000, 1, 4, 4, 0, False), (9000, 1, 8, 8, 0, False), (9000, 1, 2, 4, 50, False),
-    (9000, 1, 8, 8, 40, False), (3000, 1, 1, 4, 0, True),      # one rank with the exchange pipeline (RCCL self-test)
+    (9000, 1, 8, 8, 40, False), (9000, 1, 16, 4, 100, False), (3000, 1, 1, 4, 0, True),      # one rank with the exchange pipeline (RCCL self-test)
     (9000, 2, 1, 4, 0, True), (9001, 3, 2, 4, 30, True), (20000, 4, 4, 4, 0, True), (20000, 4, 2, 8, 60, True),
     (30000, 5, 1, 4, 0, True), (60000, 8, 4, 4, 25, True),
 ])
-def test_pair_symmetric_layout_is_complete_and_collision_free(mh, n, world, split, waves, taper, exchange):
+def test_pair_symmetric_layout_is_complete_and_collision_free(mh, n, world, split, waves, taper, exchange, diag_tri):
     """What the pair-symmetric kernel is handed (murbhip_schedule_layout, host only), for every rank of a run:
       * every ordered (i, j) interaction is applied exactly once over all items of all ranks (at the granularity of
         16 slots), with any item size mix the taper produces;
@@ -192,7 +193,7 @@ def test_pair_symmetric_layout_is_complete_and_collision_free(mh, n, world, spli
     recv = np.zeros((world, slice_), np.int64)     # what the reduce-scatter delivers: sum over ranks of their chunk for a slice
     own = np.zeros((world, slice_), np.int64)      # own-triangle row sums (exchange pipeline) / everything (one GPU)
     for r in range(world):
-        items, rows, fm, ft = mh.schedule_layout(n, world, r, split, waves, taper, 50, exchange)
+        items, rows, fm, ft = mh.schedule_layout(n, world, r, split, waves, taper, 50, exchange, diag_tri)
         assert len(items) > 0
         sets = {0: np.zeros(fm, np.int32), 1: np.zeros(ft, np.int32)}      # writers per cell
         vals = {0: np.zeros(fm, np.int64), 1: np.zeros(ft, np.int64)}      # bodies summed into the cell
@@ -200,18 +201,26 @@ def test_pair_symmetric_layout_is_complete_and_collision_free(mh, n, world, spli
         assert (np.diff(launches) >= 0).all()                              # launch order
         for i0, ln, J, flags, st, ioff, joff, launch in items:
             assert ln % (4 * waves) == 0 and ln >= 16 * waves and i0 % (4 * waves) == 0 and i0 // 1024 == (i0 + ln - 1) // 1024
-            diag = bool(flags & 1)
-            assert diag == (i0 // 1024 == J)
+            diag = i0 // 1024 == J
+            j_side, tri = not (flags & 1), bool(flags & 2)
+            assert diag or (j_side and not tri)
+            assert tri == (diag and diag_tri)
             if exchange or world > 1:
                 assert st == (1 if launch < 2 else 0)
                 assert (i0 // 1024) // tb == r                              # a rank walks its own bodies on the i side
-            count[i0 // G:(i0 + ln) // G, J * 1024 // G:(J + 1) * 1024 // G] += 1
+            # which j steps (of 128 bodies) the item evaluates, and from which one on it applies both sides
+            p_first, p_sym = ((flags >> 8) & 15, (flags >> 12) & 15) if tri else (0, 8 if diag else 0)
+            if tri:
+                assert ln <= 128 and p_first == (i0 % 1024) // 128 and p_sym == p_first + 1
+            assert j_side == (p_sym < 8)
+            j0 = J * 1024
+            count[i0 // G:(i0 + ln) // G, (j0 + 128 * p_first) // G:(j0 + 1024) // G] += 1
             sets[st][ioff:ioff + ln] += 1
-            vals[st][ioff:ioff + ln] += 1024
-            if not diag:
-                count[J * 1024 // G:(J + 1) * 1024 // G, i0 // G:(i0 + ln) // G] += 1
+            vals[st][ioff:ioff + ln] += 128 * (8 - p_first)
+            if j_side:
+                count[(j0 + 128 * p_sym) // G:(j0 + 1024) // G, i0 // G:(i0 + ln) // G] += 1
                 sets[st][joff:joff + 1024] += 1
-                vals[st][joff:joff + 1024] += ln
+                vals[st][joff + 128 * p_sym:joff + 1024] += ln
         for st in (0, 1):
             assert (sets[st] == 1).all(), (r, st, np.unique(sets[st]))
         seen = {0: np.zeros(fm, bool), 1: np.zeros(ft, bool)}
