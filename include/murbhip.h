@@ -168,7 +168,8 @@ int murbhip_sync(murbhip_ctx* ctx);
  * implementation (SimulationNBodyCUDAPropertyTracking.cu:217-304, summed there with cub).  One N^2
  * potential sweep on the device, then the per-body terms summed in fp64 on the device (256-body block sums
  * in a fixed order; the host adds the few hundred block rows); waits for enqueued steps.  In rank
- * mode the values cover the caller's own bodies only (sum them over ranks).  The accelerations of the
+ * mode the values cover the caller's own bodies only (sum them over ranks), and under the pair-symmetric plan the call
+ * is a collective (every rank evaluates its half-ring share of the pair terms, one reduce-scatter): all ranks must make it.  The accelerations of the
  * last evaluation (murbhip_download_acc) are left alone. */
 int murbhip_energy(murbhip_ctx* ctx, double* kinetic, double* potential);
 
@@ -192,6 +193,10 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  *   "taper"          variant 8: percentage (0..100) of each launch's work whose items are cut finer (the last
  *                    taper % in halves, the last taper/2 % in quarters): a shorter drain phase at the end of a launch.
  *                    -1 (default) = the plan's own choice
+ *   "sym_pass_mb"    variant 8, one GPU: budget in MiB for the partial sums of one pass (0 = default: a quarter of the
+ *                    device memory).  A problem whose partial sums exceed it (N > ~2.4 M bodies by default) is
+ *                    evaluated in several passes over ranges of j columns that share one buffer, their row sums
+ *                    accumulated in fp64 ("sym_passes" of murbhip_get_info says how many)
  *   "diag_tri"       variant 8: 1 = a diagonal block (i block = j block) is cut into pieces of 128 i bodies that only
  *                    evaluate the j bodies from their own position on (36 instead of 64 units of work per diagonal
  *                    block); 0 = the full square with the i side kept.  -1 (default) = the plan's own choice
@@ -227,7 +232,7 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  */
 int murbhip_set_option(murbhip_ctx* ctx, const char* key, long value);
 
-/* Numeric facts.  Keys: "cu_count", "clock_mhz", "n", "slots", "world", "rank", "jsplit", "variant", "cu_reserve",
+/* Numeric facts.  Keys: "cu_count", "clock_mhz", "n", "slots", "world", "rank", "jsplit", "variant", "cu_reserve", "sym_passes",
  * "workgroups", "force_launches", "force_ms_avg", "force_ms_total", "interactions_per_launch",
  * "device_bytes". */
 int murbhip_get_info(murbhip_ctx* ctx, const char* key, double* value);

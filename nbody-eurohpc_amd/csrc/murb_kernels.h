@@ -370,6 +370,8 @@ struct MurbIntegrateArgs {
     float kick_dt;           // scheme 1: length of the velocity kick ending at this step's mid point
     const float* acc_planes; // accelerations ax | ay | az (acc_stride each): row sums, or a reduce-scatter's output
     const float* acc_planes2;// optional second addend of the same shape (own-slice part that skipped the reduce-scatter)
+    const double* acc64;     // accelerations as fp64 sums ax | ay | az (acc64_stride each): multi-pass pair-symmetric evaluation
+    unsigned int acc64_stride;
     int nsched;              // persistent launches that produced accp (0, 1 or 2)
     int group_bodies;        // bodies per i group of those launches
     MurbSchedule sched[2];
@@ -407,7 +409,12 @@ __global__ __launch_bounds__(256) void murb_integrate_kernel(const MurbIntegrate
     if (s0 >= (int)a.acc_stride) return;
 
     float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-    if (a.acc_planes) {
+    if (a.acc64) {
+        const unsigned int g0 = (unsigned int)a.i_first_slot + (unsigned int)s0;
+        acc0.x = (float)a.acc64[g0]; acc1.x = (float)a.acc64[g0 + 1];
+        acc0.y = (float)a.acc64[a.acc64_stride + g0]; acc1.y = (float)a.acc64[a.acc64_stride + g0 + 1];
+        acc0.z = (float)a.acc64[2ul * a.acc64_stride + g0]; acc1.z = (float)a.acc64[2ul * a.acc64_stride + g0 + 1];
+    } else if (a.acc_planes) {
         acc0.x = a.acc_planes[s0]; acc1.x = a.acc_planes[s0 + 1];
         acc0.y = a.acc_planes[a.acc_stride + s0]; acc1.y = a.acc_planes[a.acc_stride + s0 + 1];
         acc0.z = a.acc_planes[2u * a.acc_stride + s0]; acc1.z = a.acc_planes[2u * a.acc_stride + s0 + 1];

@@ -460,6 +460,23 @@ __global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_kernel(co
             (float)total[c];
 }
 
+// Multi-pass evaluation (one GPU, rows larger than the budget): the row sums of a pass are ADDED to an fp64 accumulator
+// acc64[c * slots + slot]; blocks a pass has no rows for are not in its table and stay untouched.
+__global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_acc_kernel(const float* part, unsigned long comp_stride,
+                                                                                  const MurbSymBlockRows* rows, double* acc64,
+                                                                                  unsigned int slots)
+{
+    __shared__ double red[MURB_ROWSUM_GROUPS - 1][3][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const unsigned int wg = gridDim.x - 1 - blockIdx.x;
+    const MurbSymBlockRows br = rows[wg / (MURB_SYM_BLOCK / 64)];
+    const unsigned int in_block = (wg % (MURB_SYM_BLOCK / 64)) * 64 + lane;
+    double total[3];
+    if (!murb_sym_rowsum_slot(part, comp_stride, br, in_block, g, lane, red, total)) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc64[(unsigned long)c * slots + (unsigned long)br.out_block * MURB_SYM_BLOCK + in_block] += total[c];
+}
+
 // Single GPU: the row sum and the state update in ONE launch (a dependent launch costs ~6 us, 3 % of an
 // N = 30 000 step).  One thread per SLOT here (the stand-alone murb_integrate_kernel has one per pair): the two
 // lanes of a pair read the same records and write disjoint halves.  Same arithmetic, same rounding as

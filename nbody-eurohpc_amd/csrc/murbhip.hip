@@ -52,11 +52,19 @@ inline int nccl_rc(int r) { return r == 0 ? 0 : -(3000 + r); }   // disjoint fro
 
 // ------------------------------------------------------------------------------------ context
 // Partial rows of one group of launches (murb_kernels_sym.h): the buffer, and per block the row table its row sum reads.
+// One GPU, very large N: the items are evaluated in several passes (ranges of j columns) that reuse ONE buffer of partial
+// rows; the row sums of the passes are accumulated in fp64 (Shard::sym_acc64).  Everything else has a single pass.
+struct SymPass {
+    int item_first = 0, item_count = 0;    // items of the pass
+    int table_first = 0, table_count = 0;  // its entries of the row table
+    size_t floats = 0;                     // floats per component of its layout (= comp_stride of its launches)
+};
 struct SymSet {
     float* part = nullptr;
-    size_t comp_stride = 0;           // floats per component
+    size_t comp_stride = 0;           // floats per component (single pass)
     MurbSymBlockRows* rows = nullptr; // device copy of the table
-    int nblocks = 0;                  // entries
+    int nblocks = 0;                  // entries (all passes)
+    std::vector<SymPass> passes;      // more than one entry: multi-pass evaluation
 };
 
 struct Shard {
@@ -78,6 +86,7 @@ struct Shard {
     int sym_items_own = 0, sym_items_total = 0;   // [0, own) = own-slice triangle, the rest need the gathered positions
     int sym_split = 0, sym_waves = 0, sym_taper = -1, sym_diag_tri = -1;   // what the table was built for
     int sym_red = 0;                              // i-side reduction of the plan (kernel template parameter)
+    long sym_pass_mb = -1;                        // "sym_pass_mb" the passes were cut for
     int sym_xcd_order = -1;                       // ... and the item order ("xcd_order")
     int sym_tri_first = -1, sym_overlap = -1;     // ... and the launch boundaries inside the own-slice triangle ("tri_first_pct", "overlap")
     int sym_t1 = 0;                               // items of the triangle's first launch (exchange pipeline, overlap 1)
@@ -87,6 +96,7 @@ struct Shard {
     float* sym_send = nullptr;   // [world][3][slice]
     float* sym_recv = nullptr;   // [3][slice]
     float* sym_tri_acc = nullptr;// row sums of sym_tri [3][slice]
+    double* sym_acc64 = nullptr; // multi-pass evaluation: fp64 row sums accumulated over the passes [3][slots]
     size_t sym_bytes = 0;        // device bytes of all of the above
     hipEvent_t ev_rowsum = nullptr, ev_reduced = nullptr;
     rccl_comm_t comm_rccl = nullptr;
@@ -127,6 +137,7 @@ struct murbhip_ctx {
     int force_exchange = 0;   // run the exchange even with one rank (self-test of the RCCL binding)
     int taper = -1;           // pair-symmetric kernel: % of each launch cut into finer items (-1 = the plan's default)
     int diag_tri = -1;        // ... diagonal blocks as triangular pieces (-1 = the plan's default)
+    long sym_pass_mb = 0;     // ... one GPU: budget (MiB) for the partial rows of one pass; 0 = a quarter of the device memory
     int sym_red = -1;         // ... i-side reduction in registers (0) or through LDS (1) (-1 = the plan's default)
     int cu_reserve = 0;       // CUs masked out of the compute streams (left free for the collectives' kernels)
     int solo_shard = -1;      // >= 0: only this shard computes (timing aid: one rank's isolated timeline
@@ -255,6 +266,14 @@ long sym_items_per_rank(const murbhip_ctx* c)
     return tb * (tb + 1) / 2 + ((w - 1) / 2) * tb * tb + (w > 1 && w % 2 == 0 ? tb * ((tb + 1) / 2) : 0);
 }
 
+// One GPU: what the partial rows of one pass may take.  Problems whose rows exceed it are evaluated in several passes
+// over ranges of j columns (the rows of N = 1M take 12 GB, of 3.5M 144 GB: half of the HBM).
+size_t sym_pass_budget(const murbhip_ctx* c)
+{
+    if (c->sym_pass_mb > 0) return (size_t)c->sym_pass_mb << 20;
+    return c->device_mem ? c->device_mem / 4 : 0;
+}
+
 // Bytes of the partial rows of the pair-symmetric kernel on one rank for uniform items of 1024/split bodies
 // (12 B per row slot: three components).  One GPU: block b has split*b j rows and T-b i rows.  A rank of W: its
 // triangle (tb blocks) plus the rectangles against floor(W/2) slices: tb i rows per own block and split*tb j rows per
@@ -272,7 +291,8 @@ Plan make_plan(const murbhip_ctx* c)
     Plan p{};
     // variant 0 = auto: pair-symmetric when a GPU gets enough block pairs and its partial rows fit comfortably
     // (they grow as N^2/1024 on one GPU: 0.5 GB at 200k, 12 GB at 1M; a rank of W holds ~1/W of that), else one-sided
-    const auto fits = [&](int split) { return c->device_mem == 0 || sym_plane_bytes(c, split) < c->device_mem / 2; };
+    // (one GPU: rows beyond the budget are handled in passes, so only a rank of several has to fit them whole)
+    const auto fits = [&](int split) { return c->world == 1 || c->device_mem == 0 || sym_plane_bytes(c, split) < c->device_mem / 2; };
     if (c->variant >= 1 && c->variant <= kNumVariants) p.variant = c->variant;
     else if (c->world == 1) p.variant = (c->n >= kSymmetricMinBodies && fits(1)) ? kSymmetricVariant : kOneSidedVariant;
     else p.variant = (sym_items_per_rank(c) >= 400 && fits(1)) ? kSymmetricVariant : kOneSidedVariant;
@@ -355,8 +375,9 @@ int prof_end(murbhip_ctx* c, Shard& sh)
 
 int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p);
 int ensure_accp(murbhip_ctx* c, Shard& sh);
+int enqueue_sym_passes(murbhip_ctx* c, Shard& sh, bool potential);
 int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_planes = false,
-                       hipStream_t stream = nullptr, bool potential = false);
+                       hipStream_t stream = nullptr, bool potential = false, size_t comp_stride = 0);
 
 // Force over the tiles of `which` (0 = own slice / everything when world == 1, 1 = all but own slice).
 int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
@@ -383,6 +404,11 @@ int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
     if (p.symmetric) {   // one shard, no exchange: the whole triangle in one launch
         if (which != 0) return 0;
         RC_TRY(build_sym_schedule(c, sh, p));
+        if (sh.sym_main.passes.size() > 1) {
+            RC_TRY(enqueue_sym_passes(c, sh, false));
+            c->interactions_per_launch = (double)c->n * (double)c->n / (double)sh.sym_main.passes.size();
+            return 0;
+        }
         RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_total));   // its row sum is fused into the integrate launch
         c->interactions_per_launch = (double)c->n * (double)c->n;
         return 0;
@@ -431,12 +457,15 @@ int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int updat
     a.dt = dt;
     a.update_state = update_state;
     if (acc_from_out) a.acc_planes = sh.acc_out;   // remembered forces: nothing to sum
-    if (plan && plan->symmetric) {   // one shard, triangular schedule: row sum of the partial planes + update in one launch
+    if (plan && plan->symmetric && sh.sym_main.passes.size() > 1) {   // several passes: the sums are in the fp64 accumulator
+        a.acc64 = sh.sym_acc64;
+        a.acc64_stride = (unsigned int)c->slots;
+    } else if (plan && plan->symmetric) {   // one shard, triangular schedule: row sum of the partial planes + update in one launch
         hipLaunchKernelGGL(murb_sym_rowsum_integrate_kernel, dim3((unsigned)(c->slots / 64)), dim3(MURB_ROWSUM_THREADS), 0, sh.compute,
                            sh.sym_main.part, sh.sym_main.comp_stride, sh.sym_main.rows, a);
         return hip_rc(hipGetLastError());
     }
-    if (!acc_from_out) RC_TRY(ensure_accp(c, sh));
+    if (!acc_from_out && !a.acc64) RC_TRY(ensure_accp(c, sh));
     const unsigned pairs = (unsigned)(c->slice / 2);
     hipLaunchKernelGGL(murb_integrate_kernel, dim3((pairs + 255) / 256), dim3(256), 0, sh.compute, a);
     return hip_rc(hipGetLastError());
@@ -516,6 +545,30 @@ void free_sym_set(SymSet& st)
     st = SymSet{};
 }
 
+// Cut the pieces (j-major order) into passes at column boundaries so that no pass needs more than budget_floats of
+// partial rows per component; 0 = no limit (one pass).  Conservative estimate per column: every piece owns a j row, every
+// distinct (i block, column) pair an i row.
+std::vector<std::pair<size_t, size_t>> cut_passes(const std::vector<SymPiece>& pieces, size_t budget_floats)
+{
+    std::vector<std::pair<size_t, size_t>> out;
+    size_t first = 0, used = 0, k = 0;
+    while (k < pieces.size()) {
+        size_t e = k, rows = 0;
+        int last_block = -1;
+        while (e < pieces.size() && pieces[e].J == pieces[k].J) {   // one column
+            rows += pieces[e].j_side() ? 1 : 0;
+            if (pieces[e].i_slot0 / MURB_SYM_BLOCK != last_block) { ++rows; last_block = pieces[e].i_slot0 / MURB_SYM_BLOCK; }
+            ++e;
+        }
+        const size_t need = rows * MURB_SYM_BLOCK;
+        if (budget_floats && used > 0 && used + need > budget_floats) { out.emplace_back(first, k); first = k; used = 0; }
+        used += need;
+        k = e;
+    }
+    out.emplace_back(first, pieces.size());
+    return out;
+}
+
 // Lay out the partial rows of pieces [first, end): per block touched, an "i rows" matrix (one 1024-slot row per j block
 // its bodies were walked against) and a "j rows" matrix (one row per piece that had it as j block), end to end.  Fills
 // the pieces' output offsets into `items` and returns the per-block table; `out_of(block)` says where a block's row
@@ -578,11 +631,12 @@ struct SymHostLayout {
     std::vector<MurbSymItem> items;
     int own = 0, t1 = 0;
     std::vector<MurbSymBlockRows> table_main, table_tri;
-    size_t floats_main = 0, floats_tri = 0;
+    size_t floats_main = 0, floats_tri = 0;   // floats per component of the buffers (main: the largest pass)
+    std::vector<SymPass> passes;              // of the main set
 };
 
 void plan_sym_layout(int W, int r, int tb, int split, int waves, int taper, bool diag_tri, bool exchange_mode, int overlap,
-                     int tri_first_pct, bool xcd_order, SymHostLayout& L)
+                     int tri_first_pct, bool xcd_order, size_t budget_floats, SymHostLayout& L)
 {
     std::vector<int> flat;
     int own = 0;
@@ -610,8 +664,16 @@ void plan_sym_layout(int W, int r, int tb, int split, int waves, int taper, bool
         L.floats_tri = layout_sym_set(pieces, 0, own_pieces, waves, L.items, L.table_tri, [&](int b) { return std::make_pair(0, b - r * tb); });
         L.floats_main = layout_sym_set(pieces, own_pieces, pieces.size(), waves, L.items, L.table_main,
                                        [&](int b) { return std::make_pair(b / tb, b % tb); });
+        L.passes.assign(1, SymPass{(int)own_pieces, (int)(pieces.size() - own_pieces), 0, (int)L.table_main.size(), L.floats_main});
     } else {
-        L.floats_main = layout_sym_set(pieces, 0, pieces.size(), waves, L.items, L.table_main, [&](int b) { return std::make_pair(0, b); });
+        L.passes.clear();
+        std::vector<MurbSymBlockRows> table;
+        for (const auto& range : cut_passes(pieces, budget_floats)) {
+            const size_t floats = layout_sym_set(pieces, range.first, range.second, waves, L.items, table, [&](int b) { return std::make_pair(0, b); });
+            L.passes.push_back(SymPass{(int)range.first, (int)(range.second - range.first), (int)L.table_main.size(), (int)table.size(), floats});
+            L.table_main.insert(L.table_main.end(), table.begin(), table.end());
+            L.floats_main = std::max(L.floats_main, floats);
+        }
     }
     L.own = (int)own_pieces;
     L.t1 = t1 > 0 ? (int)piece_ends[0] : 0;
@@ -629,7 +691,7 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
     const bool exchange_mode = c->world > 1 || c->force_exchange;
     sh.sym_red = p.red;
     if (sh.sym_items && sh.sym_split == p.split && sh.sym_waves == p.waves && sh.sym_taper == p.taper && sh.sym_diag_tri == (int)p.diag_tri &&
-        sh.sym_exchange_mode == exchange_mode && sh.sym_xcd_order == c->xcd_order &&
+        sh.sym_exchange_mode == exchange_mode && sh.sym_xcd_order == c->xcd_order && sh.sym_pass_mb == c->sym_pass_mb &&
         (!exchange_mode || (sh.sym_tri_first == c->tri_first_pct && sh.sym_overlap == c->overlap)))
         return 0;
     if (sh.sym_items) {   // option changed: rebuild
@@ -645,10 +707,17 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
 
     SymHostLayout L;
     plan_sym_layout(c->world, sh.rank, (int)(c->slice / MURB_SYM_BLOCK), p.split, p.waves, p.taper, p.diag_tri, exchange_mode,
-                    c->overlap, c->tri_first_pct, c->xcd_order != 0, L);
-    if (!exchange_mode && (int)L.table_main.size() != (int)(c->slots / MURB_SYM_BLOCK)) return MURBHIP_E_STATE;   // the fused row sum + integrate walks every block
+                    c->overlap, c->tri_first_pct, c->xcd_order != 0, sym_pass_budget(c) / (3 * sizeof(float)), L);
+    if (!exchange_mode && L.passes.size() == 1 && (int)L.table_main.size() != (int)(c->slots / MURB_SYM_BLOCK))
+        return MURBHIP_E_STATE;   // the fused row sum + integrate walks every block
     RC_TRY(upload_sym_set(sh, sh.sym_tri, L.table_tri, L.floats_tri));
     RC_TRY(upload_sym_set(sh, sh.sym_main, L.table_main, L.floats_main));
+    sh.sym_main.passes = L.passes;
+    sh.sym_pass_mb = c->sym_pass_mb;
+    if (L.passes.size() > 1 && !sh.sym_acc64) {
+        HIP_TRY(hipMalloc((void**)&sh.sym_acc64, 3 * c->slots * sizeof(double)));
+        sh.bytes += 3 * c->slots * sizeof(double);
+    }
     const std::vector<MurbSymItem>& items = L.items;
     const size_t own_pieces = (size_t)L.own;
     const int W = c->world;
@@ -684,7 +753,7 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
 }
 
 int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_planes, hipStream_t stream,
-                       bool potential)
+                       bool potential, size_t comp_stride)
 {
     if (count <= 0) return 0;
     if (!stream) stream = sh.compute;
@@ -692,7 +761,7 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
     MurbSymArgs sa{};
     sa.rec = sh.rec[c->cur];
     sa.part = st.part;
-    sa.comp_stride = st.comp_stride;
+    sa.comp_stride = comp_stride ? comp_stride : st.comp_stride;
     sa.items = sh.sym_items;
     sa.item_first = first;
     sa.soft2 = c->soft2;
@@ -828,6 +897,89 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
         RC_TRY(enqueue_exchange(c, c->cur ^ 1));
         c->cur ^= 1;
     }
+    return 0;
+}
+
+// One GPU, several passes: every pass's items into the shared row buffer, its row sums added to the fp64 accumulator.
+int enqueue_sym_passes(murbhip_ctx* c, Shard& sh, bool potential)
+{
+    HIP_TRY(hipMemsetAsync(sh.sym_acc64, 0, 3 * c->slots * sizeof(double), sh.compute));
+    for (const SymPass& ps : sh.sym_main.passes) {
+        RC_TRY(enqueue_sym_launch(c, sh, ps.item_first, ps.item_count, false, nullptr, potential, ps.floats));
+        hipLaunchKernelGGL(murb_sym_rowsum_acc_kernel, dim3((unsigned)ps.table_count * (MURB_SYM_BLOCK / 64)), dim3(MURB_ROWSUM_THREADS), 0,
+                           sh.compute, sh.sym_main.part, ps.floats, sh.sym_main.rows + ps.table_first, sh.sym_acc64, (unsigned int)c->slots);
+        RC_TRY(hip_rc(hipGetLastError()));
+    }
+    return 0;
+}
+
+// The potential sweep of murbhip_energy under the half-ring schedule: the same items as a force evaluation in the
+// kernel's PHI form (phi_i += G m_j / r and phi_j += G m_i / r per pair, once), the same reduce-scatter — half the
+// pair terms of a one-sided sweep per rank.  No overlap games here: triangle, rectangles, row sums, reduce-scatter,
+// phi = received + own triangle.  A collective in one-process-per-GPU mode, like a step.
+int enqueue_potential_sym_multi(murbhip_ctx* c, const Plan& p)
+{
+    const unsigned int chunk_floats = (unsigned int)(3 * c->slice);
+    for (Shard& sh : c->shards) {
+        HIP_TRY(hipSetDevice(sh.device));
+        RC_TRY(build_sym_schedule(c, sh, p));
+        if (is_idle(c, sh)) continue;
+        if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
+        RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_own, true, nullptr, true));
+        RC_TRY(enqueue_sym_launch(c, sh, sh.sym_items_own, sh.sym_items_total - sh.sym_items_own, false, nullptr, true));
+        RC_TRY(enqueue_sym_rowsum(sh.sym_tri, sh.sym_tri_acc, (unsigned int)c->slice, sh.compute));
+        if (c->reduce_pending) {   // see enqueue_iteration_sym_multi: nobody may still be reading our send buffer
+            if (c->exchange == 0) for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.compute, peer.ev_reduced, 0));
+            else HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
+        }
+        RC_TRY(enqueue_sym_rowsum(sh.sym_main, sh.sym_send, (unsigned int)c->slice, sh.compute));
+        HIP_TRY(hipEventRecord(sh.ev_rowsum, sh.compute));
+    }
+    if (c->exchange == 1) {
+        Rccl& r = rccl();
+        for (Shard& sh : c->shards) {
+            HIP_TRY(hipSetDevice(sh.device));
+            HIP_TRY(hipStreamWaitEvent(sh.comm, sh.ev_rowsum, 0));
+        }
+        RC_TRY(nccl_rc(r.GroupStart()));
+        for (Shard& sh : c->shards) {
+            HIP_TRY(hipSetDevice(sh.device));
+            RC_TRY(nccl_rc(r.ReduceScatter(sh.sym_send, sh.sym_recv, chunk_floats, kRcclFloat, kRcclSum, sh.comm_rccl, sh.comm)));
+        }
+        RC_TRY(nccl_rc(r.GroupEnd()));
+    } else {
+        MurbPeerPtrs peers{};
+        peers.n = (int)c->shards.size();
+        for (size_t k = 0; k < c->shards.size(); ++k) peers.p[c->shards[k].rank] = c->shards[k].sym_send;
+        for (Shard& sh : c->shards) {
+            if (is_idle(c, sh)) continue;
+            HIP_TRY(hipSetDevice(sh.device));
+            for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.comm, peer.ev_rowsum, 0));
+            hipLaunchKernelGGL(murb_sym_peer_sum_kernel, dim3((chunk_floats + 255) / 256), dim3(256), 0, sh.comm, peers,
+                               (unsigned long)sh.rank * chunk_floats, chunk_floats, sh.sym_recv);
+            RC_TRY(hip_rc(hipGetLastError()));
+        }
+    }
+    for (Shard& sh : c->shards) {
+        if (is_idle(c, sh)) continue;
+        HIP_TRY(hipSetDevice(sh.device));
+        HIP_TRY(hipEventRecord(sh.ev_reduced, sh.comm));
+        HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
+        MurbIntegrateArgs a{};   // no state update: phi_out = received + own triangle (component 0 is the potential)
+        a.rec_in = sh.rec[c->cur];
+        a.rec_out = sh.rec[c->cur ^ 1];
+        a.vel = sh.vel;
+        a.acc_out = sh.phi_out;
+        a.acc_planes = sh.sym_recv;
+        a.acc_planes2 = sh.sym_tri_acc;
+        a.i_first_slot = (int)((unsigned long)sh.rank * c->slice);
+        a.count = (int)sh.count;
+        a.acc_stride = (unsigned int)c->slice;
+        a.update_state = 0;
+        hipLaunchKernelGGL(murb_integrate_kernel, dim3((unsigned)((c->slice / 2 + 255) / 256)), dim3(256), 0, sh.compute, a);
+        RC_TRY(hip_rc(hipGetLastError()));
+    }
+    c->reduce_pending = true;
     return 0;
 }
 
@@ -1066,7 +1218,7 @@ int murbhip_schedule_layout(unsigned long n, int world, int rank, int split, int
     if (MURB_SYM_BLOCK / split < 16 * waves) return MURBHIP_E_INVALID;
     SymHostLayout L;
     plan_sym_layout(world, rank, (int)(slice_slots(n, world) / MURB_SYM_BLOCK), split, waves, taper_pct & 0xff, (taper_pct & 0x100) != 0,
-                    exchange_mode != 0 || world > 1, 1, tri_first_pct, false, L);
+                    exchange_mode != 0 || world > 1, 1, tri_first_pct, false, 0, L);
     *item_count = L.items.size();
     *row_count = L.table_main.size() + L.table_tri.size();
     if (floats_main) *floats_main = L.floats_main;
@@ -1174,7 +1326,7 @@ int murbhip_destroy(murbhip_ctx* c)
         if (sh.comm) hipStreamDestroy(sh.comm);
         hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out); hipFree(sh.phi_out); hipFree(sh.mass); hipFree(sh.metrics);
         hipFree(sh.sym_items); free_sym_set(sh.sym_main); free_sym_set(sh.sym_tri);
-        hipFree(sh.sym_send); hipFree(sh.sym_recv); hipFree(sh.sym_tri_acc);
+        hipFree(sh.sym_send); hipFree(sh.sym_recv); hipFree(sh.sym_tri_acc); hipFree(sh.sym_acc64);
         if (sh.ev_rowsum) hipEventDestroy(sh.ev_rowsum);
         if (sh.ev_reduced) hipEventDestroy(sh.ev_reduced);
     }
@@ -1418,8 +1570,9 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
 {
     if (!c || !kinetic || !potential) return MURBHIP_E_INVALID;
     if (!c->uploaded) return MURBHIP_E_STATE;
-    // phi_i = sum_j GM_j / sqrt(r_ij^2 + soft^2) over ALL j (self term included) with the one-sided
-    // sweep, written to the x plane of the acceleration output
+    // phi_i = sum_j GM_j / sqrt(r_ij^2 + soft^2) over ALL j (self term included), written to the x plane of phi_out:
+    // pair-symmetric sweep where the force plan is pair-symmetric (one GPU: one launch; several ranks: the half-ring
+    // schedule with its reduce-scatter), the one-sided sweep otherwise
     RC_TRY(ensure_acc_for_readout(c));   // before the sweep: it reuses the one-sided partial rows
     Plan p{};
     p.variant = kPotentialKernel;
@@ -1432,15 +1585,32 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
     // 8 packed + 2 rsq per 4 pair terms instead of 7 + 2 per 2), through the force kernel's partial planes
     const Plan main_plan = make_plan(c);
     const bool symmetric_sweep = main_plan.symmetric && c->world == 1 && !c->force_exchange;
+    const bool symmetric_multi = main_plan.symmetric && !symmetric_sweep;   // several ranks: the half-ring form
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
         if (!sh.phi_out) {
             HIP_TRY(hipMalloc((void**)&sh.phi_out, 3 * c->slice * sizeof(float)));
             sh.bytes += 3 * c->slice * sizeof(float);
         }
+    }
+    if (symmetric_multi) RC_TRY(enqueue_potential_sym_multi(c, main_plan));
+    for (Shard& sh : c->shards) {
+        if (symmetric_multi) break;
+        HIP_TRY(hipSetDevice(sh.device));
         if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
         if (symmetric_sweep) {
             RC_TRY(build_sym_schedule(c, sh, main_plan));
+            if (sh.sym_main.passes.size() > 1) {
+                RC_TRY(enqueue_sym_passes(c, sh, true));
+                MurbIntegrateArgs a{};   // no state update: phi_out = the accumulated sums
+                a.rec_in = sh.rec[c->cur]; a.rec_out = sh.rec[c->cur ^ 1]; a.vel = sh.vel;
+                a.acc_out = sh.phi_out;
+                a.acc64 = sh.sym_acc64; a.acc64_stride = (unsigned int)c->slots;
+                a.count = (int)sh.count; a.acc_stride = (unsigned int)c->slice;
+                hipLaunchKernelGGL(murb_integrate_kernel, dim3((unsigned)((c->slice / 2 + 255) / 256)), dim3(256), 0, sh.compute, a);
+                RC_TRY(hip_rc(hipGetLastError()));
+                continue;
+            }
             RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_total, false, nullptr, true));
             RC_TRY(enqueue_sym_rowsum(sh.sym_main, sh.phi_out, (unsigned int)c->slots, sh.compute));
             continue;
@@ -1477,6 +1647,7 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     else if (k == "xcd_order") c->xcd_order = value ? 1 : 0;
     else if (k == "tri_first_pct") { if (value < 0 || value > 100) return MURBHIP_E_INVALID; c->tri_first_pct = (int)value; }
     else if (k == "taper") { if (value < -1 || value > 100) return MURBHIP_E_INVALID; c->taper = (int)value; }
+    else if (k == "sym_pass_mb") { if (value < 0) return MURBHIP_E_INVALID; c->sym_pass_mb = value; }
     else if (k == "diag_tri") { if (value < -1 || value > 1) return MURBHIP_E_INVALID; c->diag_tri = (int)value; }
     else if (k == "sym_red") { if (value < -1 || value > 1) return MURBHIP_E_INVALID; c->sym_red = (int)value; }
     else if (k == "sym_waves") { if (value != 0 && value != 4 && value != 8) return MURBHIP_E_INVALID; c->sym_waves = (int)value; }
@@ -1529,6 +1700,7 @@ int murbhip_get_info(murbhip_ctx* c, const char* key, double* value)
     else if (k == "slots") *value = (double)c->slots;
     else if (k == "world") *value = c->world;
     else if (k == "cu_reserve") *value = c->cu_reserve;
+    else if (k == "sym_passes") *value = c->shards[0].sym_main.passes.empty() ? 0.0 : (double)c->shards[0].sym_main.passes.size();
     else if (k == "rank") *value = c->shards[0].rank;
     else if (k == "jsplit") *value = p.persistent ? (double)p.sched[0].nblocks / std::max(resident_blocks(c), 1)
                                                   : (double)(p.parts_local + p.parts_remote);

@@ -176,6 +176,37 @@ def test_variants_and_jsplit_agree(gpu, O):
     assert all(np.array_equal(bits(x), bits(y)) for x, y in zip(base, again))
 
 
+@pytest.mark.parametrize("n,budget_mb,opts", [(12001, 1, {}), (30000, 4, {}), (30000, 2, {"taper": 40, "diag_tri": 1, "sym_waves": 8, "jsplit": 4}),
+                                              (20000, 1, {"integrator": 1})])
+def test_multi_pass_evaluation(gpu, O, n, budget_mb, opts):
+    """One GPU, partial sums larger than the per-pass budget ("sym_pass_mb"; by default a quarter of the HBM, reached
+    beyond ~2.4 M bodies): the items are evaluated in several passes over ranges of j columns sharing one buffer, row sums
+    accumulated in fp64.  Forced here at small N: forces, potential and a few steps against the single-pass run."""
+    s = O.init_bodies(n, "galaxy")
+    truth = O.accel_f64(s, SOFT)
+    with gpu.Simulation(n, soft=SOFT) as one, gpu.Simulation(n, soft=SOFT) as multi:
+        for sim in (one, multi):
+            sim.set_option("variant", 8)
+            for k, v in opts.items():
+                sim.set_option(k, v)
+        multi.set_option("sym_pass_mb", budget_mb)
+        for sim in (one, multi):
+            sim.upload(s)
+            sim.compute_acc()
+            sim.sync()
+        assert one.info("sym_passes") == 1 and multi.info("sym_passes") >= 3, multi.info("sym_passes")
+        assert multi.info("device_bytes") < one.info("device_bytes")
+        assert O.rel_err(multi.acc(), truth).max() <= TOL_F64_MAX
+        assert O.rel_err(multi.acc(), one.acc()).max() <= 2e-7      # same partial sums, fp64 additions regrouped
+        (k1, p1), (k2, p2) = one.energy(), multi.energy()
+        assert abs(p2 - p1) <= 1e-7 * abs(p1) and abs(k2 - k1) <= 1e-7 * abs(k1)
+        one.steps(DT, 3); multi.steps(DT, 3)
+        one.sync(); multi.sync()
+        s1, s2 = one.state(), multi.state()
+        for k in ("qx", "qy", "qz"):
+            np.testing.assert_allclose(s2[k], s1[k], rtol=2e-7, atol=1.0)
+
+
 @pytest.mark.parametrize("scheme,n", [("galaxy", 12001), ("random", 6151), ("galaxy", 30000)])
 def test_pair_symmetric_item_shapes_and_reductions(gpu, O, scheme, n):
     """The knobs of the pair-symmetric kernel's work list — tapered item sizes ("taper"), diagonal blocks as triangular
@@ -451,6 +482,22 @@ def test_energy_metric(gpu, O, scheme, n):
         many.upload(s)
         ke3, pe3 = many.energy()
         assert abs(ke3 - ke0) <= 1e-6 * abs(ke0) and abs(pe3 - pe0) <= 2e-6 * abs(pe0)
+    # sharded under the half-ring schedule: the potential sweep is pair-symmetric too (every pair term once, one
+    # reduce-scatter), before and after steps, and the step pipeline carries on unharmed after it
+    for shards in (2, 3, 4):
+        with gpu.Simulation(n, soft=SOFT, devices=[0] * shards) as many:
+            many.set_option("variant", 8)
+            many.upload(s)
+            ke3, pe3 = many.energy()
+            assert abs(ke3 - ke0) <= 1e-6 * abs(ke0) and abs(pe3 - pe0) <= 2e-6 * abs(pe0), shards
+            many.steps(DT, 5)
+            ke5, pe5 = many.energy()
+            many.steps(DT, 5)
+            ke6, pe6 = many.energy()
+            assert abs(ke6 - ke2) <= 2e-6 * abs(ke2) and abs(pe6 - pe2) <= 4e-6 * abs(pe2), shards
+            st6 = many.state()
+            for k in ("qx", "qy", "qz"):
+                np.testing.assert_allclose(st6[k], st[k], rtol=TOL_POS, atol=1.0)
 
 
 def test_long_run_stays_on_the_reference_trajectory(gpu, O):
