@@ -215,7 +215,8 @@ def test_pair_symmetric_item_shapes_and_reductions(gpu, O, scheme, n):
     s = O.init_bodies(n, scheme)
     truth = O.accel_f64(s, SOFT)
     ke, pe = O.energy_f64(s, SOFT)
-    combos = [dict(taper=t, diag_tri=d, sym_red=r, sym_waves=w, jsplit=j)
+    combos = [dict(sym_persist=1, jsplit=4, taper=30, diag_tri=1, sym_red=1), dict(sym_persist=1, jsplit=1), dict(sym_persist=1, jsplit=8, sym_red=0, taper=100)]
+    combos += [dict(taper=t, diag_tri=d, sym_red=r, sym_waves=w, jsplit=j)
               for (t, d, r, w, j) in [(0, 0, 0, 4, 4), (50, 0, 0, 4, 2), (0, 1, 0, 4, 1), (0, 1, 0, 8, 8), (0, 0, 1, 4, 2), (0, 0, 1, 8, 8),
                                       (100, 1, 1, 4, 1), (40, 1, 1, 8, 4), (30, 1, 1, 4, 16), (5, 1, 1, 4, 1), (60, 1, 0, 8, 2)]]
     for opts in combos:
