@@ -54,8 +54,6 @@ struct MurbSymArgs {
     const MurbSymItem* items;   // one per workgroup
     int item_first;             // first entry of `items` this launch evaluates
     float soft2;
-    int item_count;             // persistent form: items of this launch
-    int* ticket;                // persistent form: this launch's ticket counter (0 before the launch)
 };
 
 __device__ __forceinline__ void murb_swap32(float& a, float& b)
@@ -392,147 +390,6 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const 
 #endif
 }
 
-// ---- persistent form ------------------------------------------------------------------------------------------
-// Same items, same walk, same outputs — but the workgroups stay: 2 per CU with 8 waves each (4 waves per SIMD), and
-// every workgroup takes item after item from the table through a ticket counter instead of ending after one.
-// Why: the hardware needs ~2 us to put a new workgroup where an old one ended (resource allocation, wave launch,
-// kernel arguments, item descriptor, 16 KiB j tile from L2 into LDS before the first interaction).  With the 23-30 us
-// items of N = 30 000 (or of a rank of 8 at N = 200 000) that leaves 8-13 % of the workgroup slots empty on average
-// (tools/sym_stamps: 434-508 of 512 alive in mid-launch).  Here the turn-around is hidden: the descriptor of the next
-// item is fetched during the walk of the current one (tickets run two items ahead), its j tile is loaded into
-// registers while the j-side sums of the current item are combined, and lands in the second LDS buffer.
-// Item k goes to whoever asks first, but its outputs go to its own rows: results do not depend on the dealing.
-// Tickets: the first two items of a workgroup are blockIdx.x and blockIdx.x + gridDim.x, further ones
-// 2 * gridDim.x + atomicAdd(ticket, 1).  The counter must be 0 at launch: the row-sum kernel that consumes the
-// launch's rows resets it.
-template <int MINW, int PHI = 0, int RED = 0>
-__global__ __launch_bounds__(512, MINW) void murb_force_sym_persistent_kernel(const MurbSymArgs a)
-{
-    constexpr int WAVES = 8, THREADS = 512;
-    __shared__ float4 tileA[2][MURB_SYM_PAIRS];                 // j tiles, double-buffered
-    __shared__ float4 tileB[2][MURB_SYM_PAIRS];
-    __shared__ murb_f2 scratch[WAVES / 2][3][MURB_SYM_PAIRS];   // cross-wave combine of the j-side sums / staging (RED = 1)
-    // 2 x 16 + 48 KiB = exactly half of a CU's LDS (two workgroups per CU): the two ticket words live in the last cell of
-    // the scratch, which is dead between the first combine stage of an item and the next item's (the staging areas of
-    // RED = 1 end at byte 30 720)
-    int* const next_ticket = reinterpret_cast<int*>(&scratch[WAVES / 2 - 1][2][MURB_SYM_PAIRS - 1]);
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int count = a.item_count;
-    int k_cur = blockIdx.x, k_next = blockIdx.x + gridDim.x;
-    if (k_cur >= count) return;
-    const MurbSymItem* const table = a.items + a.item_first;
-    MurbSymItem it = table[k_cur];
-    MurbSymItem it_next = table[k_next < count ? k_next : count - 1];
-
-    // first j tile
-    {
-        const float4* src = a.rec + (unsigned long)__builtin_amdgcn_readfirstlane(it.J) * (MURB_SYM_BLOCK / MURB_TILE_BODIES) * MURB_TILE_F4;
-#pragma unroll
-        for (int k = threadIdx.x; k < 2 * MURB_TILE_F4; k += THREADS) {
-            const int tile = k / MURB_TILE_F4, in = k % MURB_TILE_F4;
-            const float4 v = src[k];
-            if (in < MURB_TILE_PAIRS) tileA[0][tile * MURB_TILE_PAIRS + in] = v;
-            else tileB[0][tile * MURB_TILE_PAIRS + in - MURB_TILE_PAIRS] = v;
-        }
-    }
-    __syncthreads();
-
-    float* const stage = reinterpret_cast<float*>(&scratch[0][0][0]) + wave * (12 * 80);
-    int cur = 0, round = 0;
-    while (true) {
-        const int i_item_slot = __builtin_amdgcn_readfirstlane(it.i_slot0);
-        const int groups_per_wave = __builtin_amdgcn_readfirstlane(it.ngroups);
-        const int flags = __builtin_amdgcn_readfirstlane(it.flags);
-        const bool no_j_side = (flags & 1) != 0, triangular = (flags & 2) != 0;
-        const int p_first = (flags >> 8) & 15, p_sym = (flags >> 12) & 15;
-
-        murb_f2 ajx[MURB_SYM_STEPS], ajy[MURB_SYM_STEPS], ajz[MURB_SYM_STEPS];
-#pragma unroll
-        for (int p = 0; p < MURB_SYM_STEPS; ++p) { ajx[p] = (murb_f2)(0.f); ajy[p] = (murb_f2)(0.f); ajz[p] = (murb_f2)(0.f); }
-        unsigned long out_off;
-        {
-            const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
-            int idx = b2 ? 8 + 2 * b4 + b5 : 4 * b3 + 2 * b4 + b5;
-            if constexpr (RED != 0) idx = (lane >> 2) < 12 ? (lane >> 2) : 11;
-            const int r = idx / 3, c = idx - 3 * r;
-            out_off = (unsigned long)c * a.comp_stride + it.ioff + r;
-        }
-        if (triangular)
-            murb_sym_walk<WAVES, 1, PHI, RED, 1>(a, tileA[cur], tileB[cur], stage, lane, wave, groups_per_wave, (unsigned int)i_item_slot,
-                                                 out_off, p_first, p_sym, ajx, ajy, ajz);
-        else
-            murb_sym_walk<WAVES, 1, PHI, RED, 0>(a, tileA[cur], tileB[cur], stage, lane, wave, groups_per_wave, (unsigned int)i_item_slot,
-                                                 out_off, 0, 0, ajx, ajy, ajz);
-
-        // the ticket of the item after next and the next item's j tile: both on their way while this item's j side is
-        // combined (the ticket is not drawn before the walk: one more live register there makes the walk spill)
-        int raw_ticket = 0;
-        if (threadIdx.x == 0) raw_ticket = atomicAdd(a.ticket, 1);
-        const bool have_next = k_next < count;
-        float4 pre0 = make_float4(0.f, 0.f, 0.f, 0.f), pre1 = pre0;
-        if (have_next) {
-            const float4* src = a.rec + (unsigned long)__builtin_amdgcn_readfirstlane(it_next.J) * (MURB_SYM_BLOCK / MURB_TILE_BODIES) * MURB_TILE_F4;
-            pre0 = src[threadIdx.x];
-            pre1 = src[threadIdx.x + THREADS];
-        }
-
-        if (!no_j_side) {
-            if constexpr (RED != 0) __syncthreads();   // the scratch doubles as the waves' staging areas
-#pragma unroll
-            for (int half = WAVES / 2; half >= 1; half >>= 1) {
-                if (wave >= half && wave < 2 * half) {
-#pragma unroll
-                    for (int p = 0; p < MURB_SYM_STEPS; ++p) {
-                        scratch[wave - half][0][p * 64 + lane] = ajx[p];
-                        scratch[wave - half][1][p * 64 + lane] = ajy[p];
-                        scratch[wave - half][2][p * 64 + lane] = ajz[p];
-                    }
-                }
-                __syncthreads();
-                if (wave < half) {
-#pragma unroll
-                    for (int p = 0; p < MURB_SYM_STEPS; ++p) {
-                        ajx[p] += scratch[wave][0][p * 64 + lane];
-                        ajy[p] += scratch[wave][1][p * 64 + lane];
-                        ajz[p] += scratch[wave][2][p * 64 + lane];
-                    }
-                }
-                if (half > 1) __syncthreads();
-            }
-            if (wave == 0) {
-                murb_f2* px = reinterpret_cast<murb_f2*>(a.part + it.joff);
-                murb_f2* py = reinterpret_cast<murb_f2*>(a.part + a.comp_stride + it.joff);
-                murb_f2* pz = reinterpret_cast<murb_f2*>(a.part + 2ul * a.comp_stride + it.joff);
-#pragma unroll
-                for (int p = 0; p < MURB_SYM_STEPS; ++p) {
-                    px[p * 64 + lane] = ajx[p];
-                    if constexpr (PHI == 0) {
-                        py[p * 64 + lane] = ajy[p];
-                        pz[p * 64 + lane] = ajz[p];
-                    }
-                }
-            }
-        }
-        if (threadIdx.x == 0) next_ticket[round & 1] = 2 * (int)gridDim.x + raw_ticket;
-        if (have_next) {   // the other buffer was last read one walk ago, and every wave has passed a barrier since
-            // thread t holds records t and t + 512 of the 1024-record block: tile 0 = records 0..511 (A then B), tile 1 = 512..1023
-            const int in0 = threadIdx.x % MURB_TILE_F4;   // = threadIdx.x
-            if (in0 < MURB_TILE_PAIRS) { tileA[cur ^ 1][in0] = pre0; tileA[cur ^ 1][MURB_TILE_PAIRS + in0] = pre1; }
-            else { tileB[cur ^ 1][in0 - MURB_TILE_PAIRS] = pre0; tileB[cur ^ 1][in0] = pre1; }
-        }
-        __syncthreads();   // next tile and ticket visible, scratch free again
-        if (!have_next) break;
-        k_cur = k_next;
-        it = it_next;
-        cur ^= 1;
-        k_next = __builtin_amdgcn_readfirstlane(next_ticket[round & 1]);
-        it_next = table[k_next < count ? k_next : count - 1];
-        ++round;
-    }
-}
-
 // ---- row sums -------------------------------------------------------------------------------------------
 // One entry per block a launch produced partial rows for: where its two matrices start (component 0), how many rows
 // each has, and where the block's totals go in the output (out[(out_slice * 3 + c) * out_slice_slots + out_block *
@@ -586,19 +443,11 @@ __device__ __forceinline__ bool murb_sym_rowsum_slot(const float* part, unsigned
 // grid.x = 16 workgroups per table entry (64 slots each).  The table is walked from its END: under the j-major item
 // order the last blocks own the most rows (the tail of a launch is cut into finer items, each with a j row of its own), and
 // their workgroups should start first.
-// Every row-sum kernel also resets the ticket counters (bits of reset_mask) of the persistent force launches whose rows it
-// consumes: they precede it on its stream and the next ones follow it.
-__device__ __forceinline__ void murb_reset_tickets(int* tickets, int reset_mask)
-{
-    if (tickets && blockIdx.x == 0 && threadIdx.x < 4 && ((reset_mask >> threadIdx.x) & 1)) tickets[threadIdx.x] = 0;
-}
-
 __global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_kernel(const float* part, unsigned long comp_stride,
                                                                               const MurbSymBlockRows* rows, float* out,
-                                                                              unsigned int out_slice_slots, int* tickets, int reset_mask)
+                                                                              unsigned int out_slice_slots)
 {
     __shared__ double red[MURB_ROWSUM_GROUPS - 1][3][64];
-    murb_reset_tickets(tickets, reset_mask);
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const unsigned int wg = gridDim.x - 1 - blockIdx.x;
     const MurbSymBlockRows br = rows[wg / (MURB_SYM_BLOCK / 64)];
@@ -615,10 +464,9 @@ __global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_kernel(co
 // acc64[c * slots + slot]; blocks a pass has no rows for are not in its table and stay untouched.
 __global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_acc_kernel(const float* part, unsigned long comp_stride,
                                                                                   const MurbSymBlockRows* rows, double* acc64,
-                                                                                  unsigned int slots, int* tickets, int reset_mask)
+                                                                                  unsigned int slots)
 {
     __shared__ double red[MURB_ROWSUM_GROUPS - 1][3][64];
-    murb_reset_tickets(tickets, reset_mask);
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const unsigned int wg = gridDim.x - 1 - blockIdx.x;
     const MurbSymBlockRows br = rows[wg / (MURB_SYM_BLOCK / 64)];
@@ -635,12 +483,10 @@ __global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_acc_kerne
 // murb_sym_rowsum_kernel followed by murb_integrate_kernel.  The table has one entry per block, in block order.
 __global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_integrate_kernel(const float* part, unsigned long comp_stride,
                                                                                         const MurbSymBlockRows* rows,
-                                                                                        const MurbIntegrateArgs a, int* tickets,
-                                                                                        int reset_mask)
+                                                                                        const MurbIntegrateArgs a)
 {
 #pragma clang fp contract(off)
     __shared__ double red[MURB_ROWSUM_GROUPS - 1][3][64];
-    murb_reset_tickets(tickets, reset_mask);
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const unsigned int wg = gridDim.x - 1 - blockIdx.x;   // last blocks first: they own the most rows
     const unsigned int s = wg * 64 + lane;

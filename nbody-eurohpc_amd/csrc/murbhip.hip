@@ -87,7 +87,6 @@ struct Shard {
     int sym_split = 0, sym_waves = 0, sym_taper = -1, sym_diag_tri = -1;   // what the table was built for
     int sym_red = 0;                              // i-side reduction of the plan (kernel template parameter)
     long sym_pass_mb = -1;                        // "sym_pass_mb" the passes were cut for
-    bool sym_persist = false;                     // persistent force launches (kernel choice; needs sym_waves == 8)
     int sym_xcd_order = -1;                       // ... and the item order ("xcd_order")
     int sym_tri_first = -1, sym_overlap = -1;     // ... and the launch boundaries inside the own-slice triangle ("tri_first_pct", "overlap")
     int sym_t1 = 0;                               // items of the triangle's first launch (exchange pipeline, overlap 1)
@@ -97,7 +96,6 @@ struct Shard {
     float* sym_send = nullptr;   // [world][3][slice]
     float* sym_recv = nullptr;   // [3][slice]
     float* sym_tri_acc = nullptr;// row sums of sym_tri [3][slice]
-    int* sym_tickets = nullptr;  // persistent force launches: ticket counters [0] triangle part 1 / everything, [1] part 2, [2] rectangles
     double* sym_acc64 = nullptr; // multi-pass evaluation: fp64 row sums accumulated over the passes [3][slots]
     size_t sym_bytes = 0;        // device bytes of all of the above
     hipEvent_t ev_rowsum = nullptr, ev_reduced = nullptr;
@@ -139,7 +137,6 @@ struct murbhip_ctx {
     int force_exchange = 0;   // run the exchange even with one rank (self-test of the RCCL binding)
     int taper = -1;           // pair-symmetric kernel: % of each launch cut into finer items (-1 = the plan's default)
     int diag_tri = -1;        // ... diagonal blocks as triangular pieces (-1 = the plan's default)
-    int sym_persist = -1;     // ... persistent workgroups (-1 = the plan's default)
     long sym_pass_mb = 0;     // ... one GPU: budget (MiB) for the partial rows of one pass; 0 = a quarter of the device memory
     int sym_red = -1;         // ... i-side reduction in registers (0) or through LDS (1) (-1 = the plan's default)
     int cu_reserve = 0;       // CUs masked out of the compute streams (left free for the collectives' kernels)
@@ -166,7 +163,6 @@ struct Plan {
     int taper;                       // ... and the share (%) of each launch whose items are cut finer ("taper")
     bool diag_tri;                   // ... diagonal blocks in triangular pieces ("diag_tri")
     int red;                         // ... i-side reduction: 0 registers, 1 LDS teams ("sym_red")
-    bool persist;                    // ... persistent workgroups taking items by ticket ("sym_persist"; 8 waves)
     MurbSchedule sched[2];           // [0] own slice (or everything), [1] the rest
 };
 
@@ -316,8 +312,7 @@ Plan make_plan(const murbhip_ctx* c)
         // tools/ab.py, interleaved, N = 30 000, wall per step: 8 waves / split 8 (round 1) 174.5 us, 8 / 4 / taper 30 /
         // triangular diagonal 170.5, 8 / 2 / taper 60 171.4; 4 waves never better.
         const bool small = c->world == 1 && c->n < 45000;
-        p.persist = c->sym_persist >= 0 ? c->sym_persist != 0 : false;
-        p.waves = p.persist ? 8 : ((c->sym_waves == 4 || c->sym_waves == 8) ? c->sym_waves : (small ? 8 : 4));
+        p.waves = (c->sym_waves == 4 || c->sym_waves == 8) ? c->sym_waves : (small ? 8 : 4);
         if (c->jsplit == 0 && c->sym_waves == 0 && small) p.split = 4;
         while (p.split > 1 && MURB_SYM_BLOCK / p.split < 16 * p.waves) p.split /= 2;   // an item is at least one group per wave
         while (p.split > 1 && !fits(p.split)) p.split /= 2;   // the rows of the split actually used must fit, too
@@ -382,7 +377,7 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p);
 int ensure_accp(murbhip_ctx* c, Shard& sh);
 int enqueue_sym_passes(murbhip_ctx* c, Shard& sh, bool potential);
 int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_planes = false,
-                       hipStream_t stream = nullptr, bool potential = false, size_t comp_stride = 0, int ticket = 0);
+                       hipStream_t stream = nullptr, bool potential = false, size_t comp_stride = 0);
 
 // Force over the tiles of `which` (0 = own slice / everything when world == 1, 1 = all but own slice).
 int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
@@ -467,7 +462,7 @@ int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int updat
         a.acc64_stride = (unsigned int)c->slots;
     } else if (plan && plan->symmetric) {   // one shard, triangular schedule: row sum of the partial planes + update in one launch
         hipLaunchKernelGGL(murb_sym_rowsum_integrate_kernel, dim3((unsigned)(c->slots / 64)), dim3(MURB_ROWSUM_THREADS), 0, sh.compute,
-                           sh.sym_main.part, sh.sym_main.comp_stride, sh.sym_main.rows, a, sh.sym_tickets, 1);
+                           sh.sym_main.part, sh.sym_main.comp_stride, sh.sym_main.rows, a);
         return hip_rc(hipGetLastError());
     }
     if (!acc_from_out && !a.acc64) RC_TRY(ensure_accp(c, sh));
@@ -695,11 +690,6 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
 {
     const bool exchange_mode = c->world > 1 || c->force_exchange;
     sh.sym_red = p.red;
-    sh.sym_persist = p.persist;
-    if (!sh.sym_tickets) {
-        HIP_TRY(hipMalloc((void**)&sh.sym_tickets, 4 * sizeof(int)));
-        HIP_TRY(hipMemsetAsync(sh.sym_tickets, 0, 4 * sizeof(int), sh.compute));
-    }
     if (sh.sym_items && sh.sym_split == p.split && sh.sym_waves == p.waves && sh.sym_taper == p.taper && sh.sym_diag_tri == (int)p.diag_tri &&
         sh.sym_exchange_mode == exchange_mode && sh.sym_xcd_order == c->xcd_order && sh.sym_pass_mb == c->sym_pass_mb &&
         (!exchange_mode || (sh.sym_tri_first == c->tri_first_pct && sh.sym_overlap == c->overlap)))
@@ -763,7 +753,7 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
 }
 
 int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_planes, hipStream_t stream,
-                       bool potential, size_t comp_stride, int ticket)
+                       bool potential, size_t comp_stride)
 {
     if (count <= 0) return 0;
     if (!stream) stream = sh.compute;
@@ -778,14 +768,7 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
     const bool timed = stream == sh.compute && !potential;   // the profiling events live on the main compute stream
     if (timed) RC_TRY(prof_begin(c, sh));
     const dim3 grid((unsigned)count);
-    if (sh.sym_persist && sh.sym_waves == 8) {   // two 8-wave workgroups per CU the stream may use, each taking items by ticket
-        sa.item_count = count;
-        sa.ticket = sh.sym_tickets + ticket;
-        const dim3 pgrid((unsigned)std::min(count, 2 * std::max(c->cu_count - c->cu_reserve, 1)));
-        if (potential) hipLaunchKernelGGL((murb_force_sym_persistent_kernel<4, 1, 0>), pgrid, dim3(512), 0, stream, sa);
-        else if (sh.sym_red == 1) hipLaunchKernelGGL((murb_force_sym_persistent_kernel<4, 0, 1>), pgrid, dim3(512), 0, stream, sa);
-        else hipLaunchKernelGGL((murb_force_sym_persistent_kernel<4, 0, 0>), pgrid, dim3(512), 0, stream, sa);
-    } else if (sh.sym_waves == 8) {
+    if (sh.sym_waves == 8) {
         if (potential) hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1, 1>), grid, dim3(512), 0, stream, sa);
         else if (sh.sym_red == 1) hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1, 0, 1>), grid, dim3(512), 0, stream, sa);
         else hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1>), grid, dim3(512), 0, stream, sa);
@@ -800,11 +783,11 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
 }
 
 // row sum of a set's partial rows into `out` (chunks of [3][out_slice_slots])
-int enqueue_sym_rowsum(const Shard& sh, const SymSet& st, float* out, unsigned int out_slice_slots, hipStream_t stream, int reset_mask)
+int enqueue_sym_rowsum(const SymSet& st, float* out, unsigned int out_slice_slots, hipStream_t stream)
 {
     if (st.nblocks <= 0) return 0;
     hipLaunchKernelGGL(murb_sym_rowsum_kernel, dim3((unsigned)st.nblocks * (MURB_SYM_BLOCK / 64)), dim3(MURB_ROWSUM_THREADS), 0, stream,
-                       st.part, st.comp_stride, st.rows, out, out_slice_slots, sh.sym_tickets, reset_mask);
+                       st.part, st.comp_stride, st.rows, out, out_slice_slots);
     return hip_rc(hipGetLastError());
 }
 
@@ -833,19 +816,19 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
             // the positions are still being gathered, then fills the gaps and the tail of the rectangles
             if (c->gather_pending || c->reduce_pending) HIP_TRY(hipStreamWaitEvent(sh.compute_low, sh.ev_integrated, 0));
             RC_TRY(enqueue_sym_launch(c, sh, 0, own, true, sh.compute_low));
-            RC_TRY(enqueue_sym_rowsum(sh, sh.sym_tri, sh.sym_tri_acc, (unsigned int)c->slice, sh.compute_low, 3));
+            RC_TRY(enqueue_sym_rowsum(sh.sym_tri, sh.sym_tri_acc, (unsigned int)c->slice, sh.compute_low));
             HIP_TRY(hipEventRecord(sh.ev_tri, sh.compute_low));
         }
         RC_TRY(enqueue_sym_launch(c, sh, 0, t1, true));
         if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
-        RC_TRY(enqueue_sym_launch(c, sh, own, sh.sym_items_total - own, false, nullptr, false, 0, 2));
+        RC_TRY(enqueue_sym_launch(c, sh, own, sh.sym_items_total - own, false));
         // nobody may still be reading our send buffer: the peer-read sums of the previous step (one process), or our
         // own previous reduce-scatter (RCCL reads it on the comm stream)
         if (c->reduce_pending) {
             if (c->exchange == 0) for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.compute, peer.ev_reduced, 0));
             else HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
         }
-        RC_TRY(enqueue_sym_rowsum(sh, sh.sym_main, sh.sym_send, (unsigned int)c->slice, sh.compute, 4));
+        RC_TRY(enqueue_sym_rowsum(sh.sym_main, sh.sym_send, (unsigned int)c->slice, sh.compute));
         HIP_TRY(hipEventRecord(sh.ev_rowsum, sh.compute));
         c->interactions_per_launch = (double)sh.count * (double)c->n;
     }
@@ -886,8 +869,8 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
         if (c->overlap == 2) {
             HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_tri, 0));
         } else {
-            RC_TRY(enqueue_sym_launch(c, sh, t1, own - t1, true, nullptr, false, 0, 1));
-            RC_TRY(enqueue_sym_rowsum(sh, sh.sym_tri, sh.sym_tri_acc, (unsigned int)c->slice, sh.compute, 3));
+            RC_TRY(enqueue_sym_launch(c, sh, t1, own - t1, true));
+            RC_TRY(enqueue_sym_rowsum(sh.sym_tri, sh.sym_tri_acc, (unsigned int)c->slice, sh.compute));
         }
         HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
         MurbIntegrateArgs a{};
@@ -924,8 +907,7 @@ int enqueue_sym_passes(murbhip_ctx* c, Shard& sh, bool potential)
     for (const SymPass& ps : sh.sym_main.passes) {
         RC_TRY(enqueue_sym_launch(c, sh, ps.item_first, ps.item_count, false, nullptr, potential, ps.floats));
         hipLaunchKernelGGL(murb_sym_rowsum_acc_kernel, dim3((unsigned)ps.table_count * (MURB_SYM_BLOCK / 64)), dim3(MURB_ROWSUM_THREADS), 0,
-                           sh.compute, sh.sym_main.part, ps.floats, sh.sym_main.rows + ps.table_first, sh.sym_acc64, (unsigned int)c->slots,
-                           sh.sym_tickets, 1);
+                           sh.compute, sh.sym_main.part, ps.floats, sh.sym_main.rows + ps.table_first, sh.sym_acc64, (unsigned int)c->slots);
         RC_TRY(hip_rc(hipGetLastError()));
     }
     return 0;
@@ -944,13 +926,13 @@ int enqueue_potential_sym_multi(murbhip_ctx* c, const Plan& p)
         if (is_idle(c, sh)) continue;
         if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
         RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_own, true, nullptr, true));
-        RC_TRY(enqueue_sym_launch(c, sh, sh.sym_items_own, sh.sym_items_total - sh.sym_items_own, false, nullptr, true, 0, 2));
-        RC_TRY(enqueue_sym_rowsum(sh, sh.sym_tri, sh.sym_tri_acc, (unsigned int)c->slice, sh.compute, 3));
+        RC_TRY(enqueue_sym_launch(c, sh, sh.sym_items_own, sh.sym_items_total - sh.sym_items_own, false, nullptr, true));
+        RC_TRY(enqueue_sym_rowsum(sh.sym_tri, sh.sym_tri_acc, (unsigned int)c->slice, sh.compute));
         if (c->reduce_pending) {   // see enqueue_iteration_sym_multi: nobody may still be reading our send buffer
             if (c->exchange == 0) for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.compute, peer.ev_reduced, 0));
             else HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
         }
-        RC_TRY(enqueue_sym_rowsum(sh, sh.sym_main, sh.sym_send, (unsigned int)c->slice, sh.compute, 4));
+        RC_TRY(enqueue_sym_rowsum(sh.sym_main, sh.sym_send, (unsigned int)c->slice, sh.compute));
         HIP_TRY(hipEventRecord(sh.ev_rowsum, sh.compute));
     }
     if (c->exchange == 1) {
@@ -1344,7 +1326,7 @@ int murbhip_destroy(murbhip_ctx* c)
         if (sh.comm) hipStreamDestroy(sh.comm);
         hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out); hipFree(sh.phi_out); hipFree(sh.mass); hipFree(sh.metrics);
         hipFree(sh.sym_items); free_sym_set(sh.sym_main); free_sym_set(sh.sym_tri);
-        hipFree(sh.sym_send); hipFree(sh.sym_recv); hipFree(sh.sym_tri_acc); hipFree(sh.sym_acc64); hipFree(sh.sym_tickets);
+        hipFree(sh.sym_send); hipFree(sh.sym_recv); hipFree(sh.sym_tri_acc); hipFree(sh.sym_acc64);
         if (sh.ev_rowsum) hipEventDestroy(sh.ev_rowsum);
         if (sh.ev_reduced) hipEventDestroy(sh.ev_reduced);
     }
@@ -1630,7 +1612,7 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
                 continue;
             }
             RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_total, false, nullptr, true));
-            RC_TRY(enqueue_sym_rowsum(sh, sh.sym_main, sh.phi_out, (unsigned int)c->slots, sh.compute, 1));
+            RC_TRY(enqueue_sym_rowsum(sh.sym_main, sh.phi_out, (unsigned int)c->slots, sh.compute));
             continue;
         }
         RC_TRY(enqueue_force(c, sh, p, 0));
@@ -1665,7 +1647,6 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     else if (k == "xcd_order") c->xcd_order = value ? 1 : 0;
     else if (k == "tri_first_pct") { if (value < 0 || value > 100) return MURBHIP_E_INVALID; c->tri_first_pct = (int)value; }
     else if (k == "taper") { if (value < -1 || value > 100) return MURBHIP_E_INVALID; c->taper = (int)value; }
-    else if (k == "sym_persist") { if (value < -1 || value > 1) return MURBHIP_E_INVALID; c->sym_persist = (int)value; }
     else if (k == "sym_pass_mb") { if (value < 0) return MURBHIP_E_INVALID; c->sym_pass_mb = value; }
     else if (k == "diag_tri") { if (value < -1 || value > 1) return MURBHIP_E_INVALID; c->diag_tri = (int)value; }
     else if (k == "sym_red") { if (value < -1 || value > 1) return MURBHIP_E_INVALID; c->sym_red = (int)value; }
