@@ -223,8 +223,9 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  *                    interconnect latencies (bench.py picks it per run, untimed)
  *   "cu_reserve"     k >= 0 (default 0): the compute streams are re-created with a CU mask that leaves the k highest
  *                    CUs (8 = one per XCD, 16 = two per XCD) to the exchange stream.  The force kernels otherwise fill
- *                    every CU, and a collective's kernel (RCCL) has to wait for one of their workgroups to retire;
- *                    costs k/256 of the force rate.  bench.py picks it per run for N > 1, like "tri_first_pct"
+ *                    every CU, and a collective's kernel (RCCL) has to wait ~0.1 ms for one of their workgroups to retire
+ *                    (7 us with k = 8); but dispatch on a masked queue is slower: 6-8 % on long force launches, much more
+ *                    on short ones.  bench.py times it per run for N > 1, like "tri_first_pct"
  *   "solo_shard"     r >= 0: in a sharded context only shard r launches force work (timing aid: the
  *                    isolated per-step timeline of one rank of W; results are meaningless).  -1 = off
  *   "force_exchange" 1: run the position exchange even with a single rank/shard (self-test of the

@@ -36,6 +36,9 @@
 #define MURB_SYM_PAIRS (MURB_SYM_BLOCK / 2)       /* 512 pairs                        */
 #define MURB_SYM_STEPS (MURB_SYM_PAIRS / 64)      /* 8 pair-vectors per lane          */
 #define MURB_SYM_R 4                              /* i bodies per group               */
+#ifndef MURB_SYM_STEP_BARRIER
+#define MURB_SYM_STEP_BARRIER 1
+#endif
 
 // One workgroup's work: the bodies [i_slot0, i_slot0 + ngroups * WAVES * R) against j block J.
 struct MurbSymItem {
@@ -247,7 +250,7 @@ __device__ __forceinline__ void murb_sym_walk(const MurbSymArgs& a, const float4
                                           ajz[p]);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);   // one step at a time: bounds the live temporaries
+            if (MURB_SYM_STEP_BARRIER) __builtin_amdgcn_sched_barrier(0);   // one step at a time: bounds the live temporaries
         }
 
         // i side: 12 sums -> lanes, one float per (body, component) -> the item's i row
