@@ -105,6 +105,29 @@ def test_ranks_match_single_gpu(gpu, O, tmp_path, world, n, variant, overlap, js
     assert abs(sum(float(d["pe"]) for d in ranks) - pe) <= 1e-5 * abs(pe)
 
 
+@pytest.mark.parametrize("world,n,overlap", [(4, 20000, 1), (3, 15000, 2)])
+def test_long_rank_mode_run_with_asynchronous_collectives(gpu, O, tmp_path, world, n, overlap):
+    """300 steps, every one with a reduce-scatter and an all-gather that only ENQUEUE work on the library's exchange stream
+    (the stand-in's async mode): a missing dependency between the compute and exchange streams — reading positions before
+    they are gathered, overwriting the send buffer before it is reduced, integrating before the sums arrive — has 600
+    chances to show as a divergence from the single-GPU trajectory.  All ranks must end with bit-identical positions."""
+    steps = 300
+    ranks = run_ranks(tmp_path, world, n, steps, 8, overlap=overlap, mode="async")
+    s = O.init_bodies(n, "galaxy")
+    with gpu.Simulation(n, soft=SOFT) as one:
+        one.upload(s)
+        one.steps(DT, steps); one.sync()
+        ref = one.state()
+    scale = max(np.abs(ref[k]).max() for k in ("qx", "qy", "qz"))
+    for d in ranks:
+        for k in ("qx", "qy", "qz"):
+            assert np.isfinite(d[k]).all()
+            assert np.abs(d[k] - ref[k]).max() <= 2e-5 * scale, k      # two fp32 summation orders, 300 steps apart
+    for d in ranks[1:]:
+        for k in ("qx", "qy", "qz"):
+            assert np.array_equal(d[k].view(np.uint32), ranks[0][k].view(np.uint32))
+
+
 def test_ranks_leapfrog(gpu, O, tmp_path):
     """The closing half kick on read-out is a collective in rank mode (one more force evaluation on every rank)."""
     world, n, steps = 3, 9000, 4
