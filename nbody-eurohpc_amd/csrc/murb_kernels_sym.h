@@ -480,8 +480,8 @@ __global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_acc_kerne
     for (int c = 0; c < 3; ++c) acc64[(unsigned long)c * slots + (unsigned long)br.out_block * MURB_SYM_BLOCK + in_block] += total[c];
 }
 
-// Single GPU: the row sum and the state update in ONE launch (a dependent launch costs ~6 us, 3 % of an
-// N = 30 000 step).  One thread per SLOT here (the stand-alone murb_integrate_kernel has one per pair): the two
+// The row sum and the state update in ONE launch (a dependent launch costs ~6 us, 3 % of an N = 30 000 step): one
+// GPU, everything; a rank of several, the own-slice triangle's rows plus the reduce-scatter's result (a.acc_planes).  One thread per SLOT here (the stand-alone murb_integrate_kernel has one per pair): the two
 // lanes of a pair read the same records and write disjoint halves.  Same arithmetic, same rounding as
 // murb_sym_rowsum_kernel followed by murb_integrate_kernel.  The table has one entry per block, in block order.
 __global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_integrate_kernel(const float* part, unsigned long comp_stride,
@@ -496,7 +496,10 @@ __global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_integrate
     const MurbSymBlockRows br = rows[wg / (MURB_SYM_BLOCK / 64)];
     double total[3];
     if (!murb_sym_rowsum_slot(part, comp_stride, br, s % MURB_SYM_BLOCK, g, lane, red, total)) return;
-    const float ax = (float)total[0], ay = (float)total[1], az = (float)total[2];
+    float ax = (float)total[0], ay = (float)total[1], az = (float)total[2];
+    if (a.acc_planes) {   // a rank of several: the other ranks' (and the own rectangles') share, as reduced and scattered
+        ax += a.acc_planes[s]; ay += a.acc_planes[a.acc_stride + s]; az += a.acc_planes[2u * a.acc_stride + s];
+    }
     a.acc_out[s] = ax;
     a.acc_out[a.acc_stride + s] = ay;
     a.acc_out[2u * a.acc_stride + s] = az;

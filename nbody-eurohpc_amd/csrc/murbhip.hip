@@ -870,7 +870,6 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
             HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_tri, 0));
         } else {
             RC_TRY(enqueue_sym_launch(c, sh, t1, own - t1, true));
-            RC_TRY(enqueue_sym_rowsum(sh.sym_tri, sh.sym_tri_acc, (unsigned int)c->slice, sh.compute));
         }
         HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
         MurbIntegrateArgs a{};
@@ -880,7 +879,6 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
         a.accp = sh.accp;
         a.acc_out = sh.acc_out;
         a.acc_planes = sh.sym_recv;
-        a.acc_planes2 = sh.sym_tri_acc;
         a.scheme = c->integrator;
         a.kick_dt = leapfrog_kick(c, dt);
         a.i_first_slot = (int)((unsigned long)sh.rank * c->slice);
@@ -888,7 +886,13 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
         a.acc_stride = (unsigned int)c->slice;
         a.dt = dt;
         a.update_state = update_state;
-        hipLaunchKernelGGL(murb_integrate_kernel, dim3((unsigned)((c->slice / 2 + 255) / 256)), dim3(256), 0, sh.compute, a);
+        if (c->overlap == 2) {   // the triangle's row sums were taken on the other stream
+            a.acc_planes2 = sh.sym_tri_acc;
+            hipLaunchKernelGGL(murb_integrate_kernel, dim3((unsigned)((c->slice / 2 + 255) / 256)), dim3(256), 0, sh.compute, a);
+        } else {                 // row sum of the triangle's rows + the reduced share + state update in one launch
+            hipLaunchKernelGGL(murb_sym_rowsum_integrate_kernel, dim3((unsigned)(c->slice / 64)), dim3(MURB_ROWSUM_THREADS), 0, sh.compute,
+                               sh.sym_tri.part, sh.sym_tri.comp_stride, sh.sym_tri.rows, a);
+        }
         RC_TRY(hip_rc(hipGetLastError()));
         if (!update_state) HIP_TRY(hipEventRecord(sh.ev_integrated, sh.compute));   // else enqueue_exchange records it
     }
