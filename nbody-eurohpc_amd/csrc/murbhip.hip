@@ -792,15 +792,14 @@ int enqueue_sym_rowsum(const SymSet& st, float* out, unsigned int out_slice_slot
 }
 
 // One iteration under the half-ring schedule.  Per shard, on the compute stream unless noted:
-//   T1  first half of the own-slice triangle          (needs no remote data: overlaps the position gather)
+//   T1  first part of the own-slice triangle          (needs no remote data: overlaps the position gather)
 //       wait: positions of the previous step gathered
-//   R   rectangles against the other slices            -> big planes
-//   SR  row sum of the big planes -> send chunks       (own-slice chunk = i-side sums of the rectangles)
+//   R   rectangles against the other slices            -> the rectangles' rows (sym_main)
+//   SR  row sum of those rows -> send chunks           (own-slice chunk = i-side sums of the rectangles)
 //       [comm stream] reduce-scatter of the chunks -> recv          (overlaps T2)
-//   T2  second half of the own-slice triangle          -> own-slice planes
-//   ST  row sum of the own-slice planes -> tri_acc
+//   T2  rest of the own-slice triangle                 -> the triangle's rows (sym_tri)
 //       wait: reduce-scatter done
-//   I   integrate with acc = recv + tri_acc ; then [comm stream] all-gather of the new positions
+//   I   row sum of the triangle's rows + recv, state update: one launch ; then [comm stream] all-gather of the new positions
 // The triangle never enters the reduce-scatter (it only touches the rank's own bodies), which is what
 // lets half of it hide the collective's latency.
 int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int update_state)
