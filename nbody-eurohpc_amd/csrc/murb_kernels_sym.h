@@ -293,7 +293,6 @@ __device__ __forceinline__ void murb_sym_walk(const MurbSymArgs& a, const float4
 template <int MINW, int WAVES = 4, int ILOAD = 0, int PHI = 0, int RED = 0>
 __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const MurbSymArgs a)
 {
-    constexpr int R = MURB_SYM_R;
     constexpr int THREADS = 64 * WAVES;
     __shared__ float4 tileA[MURB_SYM_PAIRS];                    // {x0,x1,y0,y1} of the J block
     __shared__ float4 tileB[MURB_SYM_PAIRS];                    // {z0,z1,gm0,gm1}
