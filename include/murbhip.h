@@ -233,7 +233,7 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  */
 int murbhip_set_option(murbhip_ctx* ctx, const char* key, long value);
 
-/* Numeric facts.  Keys: "cu_count", "clock_mhz", "n", "slots", "world", "rank", "jsplit", "variant", "cu_reserve", "sym_passes",
+/* Numeric facts.  Keys: "cu_count", "clock_mhz", "n", "slots", "world", "rank", "jsplit", "variant", "cu_reserve", "sym_passes", "sym_waves", "taper",
  * "workgroups", "force_launches", "force_ms_avg", "force_ms_total", "interactions_per_launch",
  * "device_bytes". */
 int murbhip_get_info(murbhip_ctx* ctx, const char* key, double* value);

@@ -694,10 +694,9 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
         sh.sym_exchange_mode == exchange_mode && sh.sym_xcd_order == c->xcd_order && sh.sym_pass_mb == c->sym_pass_mb &&
         (!exchange_mode || (sh.sym_tri_first == c->tri_first_pct && sh.sym_overlap == c->overlap)))
         return 0;
-    if (sh.sym_items) {   // option changed: rebuild
-        HIP_TRY(hipStreamSynchronize(sh.compute));
-        HIP_TRY(hipStreamSynchronize(sh.compute_low));
-        HIP_TRY(hipStreamSynchronize(sh.comm));
+    if (sh.sym_items) {   // option changed: rebuild.  Everything in flight first — also on the other shards of this process,
+        RC_TRY(murbhip_sync(c));   // whose peer-read sums of the previous step may still be reading our send buffer
+        HIP_TRY(hipSetDevice(sh.device));
     }
     hipFree(sh.sym_items); sh.sym_items = nullptr;
     free_sym_set(sh.sym_main);
@@ -1705,8 +1704,11 @@ int murbhip_get_info(murbhip_ctx* c, const char* key, double* value)
     else if (k == "cu_reserve") *value = c->cu_reserve;
     else if (k == "sym_passes") *value = c->shards[0].sym_main.passes.empty() ? 0.0 : (double)c->shards[0].sym_main.passes.size();
     else if (k == "rank") *value = c->shards[0].rank;
-    else if (k == "jsplit") *value = p.persistent ? (double)p.sched[0].nblocks / std::max(resident_blocks(c), 1)
-                                                  : (double)(p.parts_local + p.parts_remote);
+    else if (k == "jsplit") *value = p.symmetric ? (double)p.split
+                                     : p.persistent ? (double)p.sched[0].nblocks / std::max(resident_blocks(c), 1)
+                                                    : (double)(p.parts_local + p.parts_remote);
+    else if (k == "sym_waves") *value = p.symmetric ? p.waves : 0;
+    else if (k == "taper") *value = p.symmetric ? p.taper : 0;
     else if (k == "workgroups") *value = p.persistent ? p.sched[0].nblocks + (c->world > 1 ? p.sched[1].nblocks : 0) : 0;
     else if (k == "variant") *value = p.variant;
     else if (k == "interactions_per_launch") *value = c->interactions_per_launch;
