@@ -172,12 +172,15 @@ __device__ __forceinline__ void murb_sym_walk(const MurbSymArgs& a, const float4
 {
     constexpr int R = MURB_SYM_R;
     const float soft2 = a.soft2;
-    const int stage_wr = (lane >> 4) * 20 + (lane & 15);
-    const int stage_rd = ((lane >> 2) < 12 ? (lane >> 2) : 11) * 80 + (lane & 3) * 20;
+    // staging rows of 64 floats at a stride of 80: lane L writes entry L (64 consecutive floats: no bank conflict); team lane
+    // q of value k reads the four float4 at entries 16 m + 4 q (m = 0..3): the eight lanes served together (two values x
+    // four q) start 4 floats apart within a row and the odd row is 80 = 16 (mod 32) floats further: 32 distinct banks
+    const int stage_wr = lane;
+    const int stage_rd = ((lane >> 2) < 12 ? (lane >> 2) : 11) * 80 + (lane & 3) * 4;
     // RED = 1: four lanes per value add up its 64 staged entries
     const auto team_sum = [&](int g_of) {
         const float4* src = reinterpret_cast<const float4*>(stage + stage_rd);
-        const float4 t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3];
+        const float4 t0 = src[0], t1 = src[4], t2 = src[8], t3 = src[12];
         murb_f2 s2 = (murb_f2){t0.x, t0.y} + (murb_f2){t0.z, t0.w};
         s2 += (murb_f2){t1.x, t1.y}; s2 += (murb_f2){t1.z, t1.w};
         s2 += (murb_f2){t2.x, t2.y}; s2 += (murb_f2){t2.z, t2.w};
@@ -286,8 +289,9 @@ __device__ __forceinline__ void murb_sym_walk(const MurbSymArgs& a, const float4
 // written to component 0 only (the cells of components 1 and 2 keep whatever they held; their row sums are not used).
 // RED = 0: the 12 i-side sums of a group are folded in registers (murb_reduce12: 39 VALU instructions).  RED = 1: through
 // LDS — each lane adds the two halves of its 12 sums and stores them (12 ds_write_b32 into a per-wave area aliased with
-// the end-of-item combine scratch, rows padded so that the reads are conflict-free), then teams of four lanes sum one
-// value's 64 entries (4 ds_read_b128 and 7 packed adds per lane, one add, two DPP adds): 22 VALU instructions per group.
+// the end-of-item combine scratch, rows of 64 floats at a stride of 80 so that neither the writes nor the reads conflict),
+// then teams of four lanes sum one value's 64 entries (4 ds_read_b128 and 7 packed adds per lane, one add, two DPP adds):
+// 22 VALU instructions per group.
 // (Taking the team sums one group later, in the middle of the next group's sweep, to cover the LDS round trip, measured
 // 2 % SLOWER than RED = 1 at N = 200 000 and was dropped.)
 template <int MINW, int WAVES = 4, int ILOAD = 0, int PHI = 0, int RED = 0>
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const 
         const int r = idx / 3, c = idx - 3 * r;
         out_off = (unsigned long)c * a.comp_stride + it.ioff + r;
     }
-    // RED = 1: this wave's staging area (12 rows of 64 floats, a quarter row padded to 20 floats, a row to 80)
+    // RED = 1: this wave's staging area (12 rows of 64 floats at a stride of 80)
     float* const stage = reinterpret_cast<float*>(&scratch[0][0][0]) + wave * (12 * 80);
     if (triangular)
         murb_sym_walk<WAVES, ILOAD, PHI, RED, 1>(a, tileA, tileB, stage, lane, wave, groups_per_wave, (unsigned int)i_item_slot, out_off,
