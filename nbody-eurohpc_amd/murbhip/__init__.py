@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "..", "lib", "libmurbhip.so")
+LIB_PATH = os.environ.get("MURBHIP_LIBRARY") or os.path.join(_HERE, "..", "lib", "libmurbhip.so")   # override: lab builds
 G = np.float32(6.67384e-11)   # reference SimulationNBodyInterface.hpp:18
 
 _fp = C.POINTER(C.c_float)
