@@ -496,8 +496,9 @@ def test_energy_metric(gpu, O, scheme, n):
             ke6, pe6 = many.energy()
             assert abs(ke6 - ke2) <= 2e-6 * abs(ke2) and abs(pe6 - pe2) <= 4e-6 * abs(pe2), shards
             st6 = many.state()
-            for k in ("qx", "qy", "qz"):
-                np.testing.assert_allclose(st6[k], st[k], rtol=TOL_POS, atol=1.0)
+            scale = max(np.abs(st[k]).max() for k in ("qx", "qy", "qz"))
+            for k in ("qx", "qy", "qz"):   # ten steps, two summation orders: relative to the size of the system, not of the component
+                assert np.abs(st6[k] - st[k]).max() <= TOL_POS * scale, (shards, k)
 
 
 def test_long_run_stays_on_the_reference_trajectory(gpu, O):
