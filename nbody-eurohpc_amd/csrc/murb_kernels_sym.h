@@ -21,7 +21,7 @@
 // Partial sums: for every block B the launch owns two small matrices of 1024-slot rows, "i rows" (one per j block
 // that some item of block B's bodies walked against: the i-side sums) and "j rows" (one per item that had B as its j
 // block: the j-side sums), laid end to end in one buffer, once per component (x, y, z).  The host builds the layout
-// together with the item table (murbhip.hip: SymLayout) and hands every item the offsets of its two outputs, so the
+// together with the item table (murbhip.hip: plan_sym_layout) and hands every item the offsets of its two outputs, so the
 // kernel knows nothing about it; every cell has exactly one writer per launch, rows exist only where somebody writes
 // (a rank of a multi-GPU run holds just the rows of its own items), and a row sum in fp64 in a fixed order
 // (murb_sym_rowsum_*) turns them into accelerations.  No atomics: bit-reproducible.
