@@ -11,6 +11,10 @@
 //                    Nothing is drained: a consumer that forgets to wait for the collective's stream reads
 //                    stale data and the comparison with the single-GPU run fails — the property a synchronous
 //                    stand-in cannot check.
+//   solo             (MURB_MOCK_SOLO=1, tools/solo_rank.py) ONE rank of a W-rank communicator runs without its peers: nobody
+//                    is waited for, the all-gather leaves the caller's own slice where it is and the reduce-scatter
+//                    copies the caller's own block of its own contribution device-to-device.  Results are meaningless;
+//                    what it gives is the step time of one real rank process (its own three streams) without the wire.
 //   sync             each call drains its stream, stages through host memory and returns when the result
 //                    is in place (the behaviour of round 1).
 // Loaded only when MURBHIP_RCCL_LIBRARY points at it (tests/test_rank_mode_mock.py).
@@ -77,6 +81,12 @@ std::string segment_name(const Id& id)
 }
 constexpr int kOk = 0, kInvalid = 4, kSystem = 2;
 
+bool solo_mode()
+{
+    static const bool a = [] { const char* m = std::getenv("MURB_MOCK_SOLO"); return m && *m && *m != '0'; }();
+    return a;
+}
+
 bool async_mode()
 {
     static const bool a = [] {
@@ -140,6 +150,7 @@ int ncclCommInitRank(void** out, int nranks, Id id, int rank)
     if (!out || nranks < 1 || rank < 0 || rank >= nranks || std::memcmp(id.bytes, "MOCKRCCL", 8) != 0) return kInvalid;
     Comm* c = new Comm;
     c->rank = rank; c->nranks = nranks; c->name = segment_name(id);
+    if (solo_mode()) { *out = c; return kOk; }   // no peers, no shared segment
     const size_t bytes = sizeof(Segment) + kCapacity;
     int fd = -1;
     if (rank == 0) {
@@ -214,6 +225,7 @@ int ncclCommDestroy(void* comm)
         return kOk;
     }
     (void)hipDeviceSynchronize();   // async mode: host functions of this communicator may still be queued
+    if (!c->seg) { delete c; return kOk; }   // solo mode
     pthread_barrier_wait(&c->seg->barrier);
     if (c->pinned) (void)hipHostUnregister(c->seg->data);
     munmap(c->seg, sizeof(Segment) + kCapacity);
@@ -234,6 +246,7 @@ int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* c
         return kOk;
     }
     if (!c || dtype != 7 || bytes * c->nranks > kCapacity) return kInvalid;
+    if (solo_mode()) return kOk;   // in place: the caller's slice is where it belongs, the others never arrive
     if (async_mode()) {
         if (hipMemcpyAsync(c->seg->data + (size_t)c->rank * bytes, send, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return kSystem;
         if (hipLaunchHostFunc(stream, host_barrier, c) != hipSuccess) return kSystem;
@@ -262,6 +275,9 @@ int ncclReduceScatter(const void* send, void* recv, size_t recvcount, int dtype,
     if (!c) return kInvalid;
     const size_t block = recvcount * 4, mine = block * c->nranks;
     if (dtype != 7 || op != 0 || mine * c->nranks + block * c->nranks > kCapacity) return kInvalid;
+    if (solo_mode())
+        return hipMemcpyAsync(recv, static_cast<const char*>(send) + (size_t)c->rank * block, block, hipMemcpyDeviceToDevice, stream) == hipSuccess
+                   ? kOk : kSystem;
     if (async_mode()) {
         if (hipMemcpyAsync(c->seg->data + (size_t)c->rank * mine, send, mine, hipMemcpyDeviceToHost, stream) != hipSuccess) return kSystem;
         if (hipLaunchHostFunc(stream, host_barrier, c) != hipSuccess) return kSystem;
