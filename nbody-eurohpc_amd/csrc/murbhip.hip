@@ -278,7 +278,7 @@ size_t sym_pass_budget(const murbhip_ctx* c)
 // (12 B per row slot: three components).  One GPU: block b has split*b j rows and T-b i rows.  A rank of W: its
 // triangle (tb blocks) plus the rectangles against floor(W/2) slices: tb i rows per own block and split*tb j rows per
 // far block at most.
-size_t sym_plane_bytes(const murbhip_ctx* c, int split)
+size_t sym_row_bytes(const murbhip_ctx* c, int split)
 {
     const size_t tb = c->slice / MURB_SYM_BLOCK, w = (size_t)c->world, far = w / 2;
     size_t rows = tb * tb + (size_t)(split - 1) * tb * (tb - 1) / 2;
@@ -292,7 +292,7 @@ Plan make_plan(const murbhip_ctx* c)
     // variant 0 = auto: pair-symmetric when a GPU gets enough block pairs and its partial rows fit comfortably
     // (they grow as N^2/1024 on one GPU: 0.5 GB at 200k, 12 GB at 1M; a rank of W holds ~1/W of that), else one-sided
     // (one GPU: rows beyond the budget are handled in passes, so only a rank of several has to fit them whole)
-    const auto fits = [&](int split) { return c->world == 1 || c->device_mem == 0 || sym_plane_bytes(c, split) < c->device_mem / 2; };
+    const auto fits = [&](int split) { return c->world == 1 || c->device_mem == 0 || sym_row_bytes(c, split) < c->device_mem / 2; };
     if (c->variant >= 1 && c->variant <= kNumVariants) p.variant = c->variant;
     else if (c->world == 1) p.variant = (c->n >= kSymmetricMinBodies && fits(1)) ? kSymmetricVariant : kOneSidedVariant;
     else p.variant = (sym_items_per_rank(c) >= 400 && fits(1)) ? kSymmetricVariant : kOneSidedVariant;
@@ -376,7 +376,7 @@ int prof_end(murbhip_ctx* c, Shard& sh)
 int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p);
 int ensure_accp(murbhip_ctx* c, Shard& sh);
 int enqueue_sym_passes(murbhip_ctx* c, Shard& sh, bool potential);
-int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_planes = false,
+int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_rows = false,
                        hipStream_t stream = nullptr, bool potential = false, size_t comp_stride = 0);
 
 // Force over the tiles of `which` (0 = own slice / everything when world == 1, 1 = all but own slice).
@@ -460,7 +460,7 @@ int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int updat
     if (plan && plan->symmetric && sh.sym_main.passes.size() > 1) {   // several passes: the sums are in the fp64 accumulator
         a.acc64 = sh.sym_acc64;
         a.acc64_stride = (unsigned int)c->slots;
-    } else if (plan && plan->symmetric) {   // one shard, triangular schedule: row sum of the partial planes + update in one launch
+    } else if (plan && plan->symmetric) {   // one shard, triangular schedule: row sum of the partial rows + update in one launch
         hipLaunchKernelGGL(murb_sym_rowsum_integrate_kernel, dim3((unsigned)(c->slots / 64)), dim3(MURB_ROWSUM_THREADS), 0, sh.compute,
                            sh.sym_main.part, sh.sym_main.comp_stride, sh.sym_main.rows, a);
         return hip_rc(hipGetLastError());
@@ -751,12 +751,12 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
     return 0;
 }
 
-int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_planes, hipStream_t stream,
+int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_rows, hipStream_t stream,
                        bool potential, size_t comp_stride)
 {
     if (count <= 0) return 0;
     if (!stream) stream = sh.compute;
-    const SymSet& st = own_triangle_planes ? sh.sym_tri : sh.sym_main;
+    const SymSet& st = own_triangle_rows ? sh.sym_tri : sh.sym_main;
     MurbSymArgs sa{};
     sa.rec = sh.rec[c->cur];
     sa.part = st.part;
@@ -1584,7 +1584,7 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
         p.parts_remote = c->world > 1 ? std::max(1, std::min<int>(auto_parts(c, 1, c->slice, tiles_remote), kMaxParts / 2)) : 0;
     }
     // one shard on the pair-symmetric plan: the sweep is pair-symmetric too (phi_i += G m_j / r, phi_j += G m_i / r:
-    // 8 packed + 2 rsq per 4 pair terms instead of 7 + 2 per 2), through the force kernel's partial planes
+    // 8 packed + 2 rsq per 4 pair terms instead of 7 + 2 per 2), through the force kernel's partial rows
     const Plan main_plan = make_plan(c);
     const bool symmetric_sweep = main_plan.symmetric && c->world == 1 && !c->force_exchange;
     const bool symmetric_multi = main_plan.symmetric && !symmetric_sweep;   // several ranks: the half-ring form
