@@ -485,8 +485,9 @@ __global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_acc_kerne
 
 // The row sum and the state update in ONE launch (a dependent launch costs ~6 us, 3 % of an N = 30 000 step): one
 // GPU, everything; a rank of several, the own-slice triangle's rows plus the reduce-scatter's result (a.acc_planes).
-// One thread per SLOT here (the stand-alone murb_integrate_kernel has one per pair): the two lanes of a pair read the same records and write disjoint halves.  Same arithmetic, same rounding as
-// murb_sym_rowsum_kernel followed by murb_integrate_kernel.  The table has one entry per block, in block order.
+// One thread per SLOT here (the stand-alone murb_integrate_kernel has one per pair): the two lanes of a pair read the
+// same records and write disjoint halves.  Same arithmetic, same rounding as murb_sym_rowsum_kernel followed by
+// murb_integrate_kernel.  The table has one entry per block, in block order.
 __global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_integrate_kernel(const float* part, unsigned long comp_stride,
                                                                                         const MurbSymBlockRows* rows,
                                                                                         const MurbIntegrateArgs a)
