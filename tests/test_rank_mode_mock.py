@@ -194,6 +194,24 @@ def test_bench_py_launches_its_own_ranks(gpu):
     assert chk["positions_identical_on_all_ranks"] and chk["finite"] and chk["max_position_diff_rel"] < 1e-5, chk
 
 
+def test_bench_py_watchdog_reports_a_stuck_phase(gpu):
+    """N > 1: a phase of bench.py that makes no progress within its limit (here: a limit no phase can meet) must end the
+    run with ONE JSON line carrying an "error" key from rank 0 and a non-zero exit code — not a silent hang."""
+    import json
+    env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK, MURB_BENCH_BACKEND="gloo", MURB_BENCH_SHARE_GPU="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", MURB_BENCH_PHASE_LIMIT_S="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bodies", "40000", "--steps", "5",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, (r.stdout, r.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["value"] is None and "no progress in phase" in d["error"] and d["phase"]
+    assert "giving up" in r.stderr
+
+
 @pytest.mark.parametrize("shards,n,variant,overlap", [(2, 9000, 8, 1), (3, 9001, 8, 0), (4, 20000, 8, 1), (3, 9000, 1, 1)])
 def test_one_process_several_shards_over_rccl_calls(gpu, shards, n, variant, overlap):
     """`--im hip+tile+multi` on a multi-GPU node = murbhip_create_sharded(..., exchange = RCCL): ncclCommInitAll and
