@@ -1146,7 +1146,7 @@ void pack_records(const murbhip_ctx* c, const float* x, const float* y, const fl
 // ===================================================================================== C ABI
 extern "C" {
 
-int murbhip_version(void) { return 100; }
+int murbhip_version(void) { return 101; }   // 1.01: murbhip_schedule_layout, the round-2 options
 
 const char* murbhip_error_string(int code)
 {
