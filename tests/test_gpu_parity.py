@@ -19,6 +19,7 @@ Tolerances (fp32; relative vector error per body, |a_gpu - a_ref| / |a_ref|, SUR
   * integrator alone: bit exact.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -660,6 +661,27 @@ def test_murb_hip_cli_output(gpu):
     ms, fps, gf = float(m.group(1)), float(m.group(2)), float(m.group(3))
     assert abs(fps - 20 * 1000.0 / ms) / fps < 1e-2
     assert abs(gf - 20.0 * 30000.0 ** 2 * fps / 1024 ** 3) / gf < 2e-2       # Perf.cpp:28 definition
+
+
+def test_plugin_falls_back_to_peer_copies_without_rccl(gpu):
+    """SimulationNBodyHIP over several devices asks for the RCCL exchange; where librccl cannot be loaded (here:
+    MURBHIP_RCCL_LIBRARY=none) murbhip_create_sharded answers MURBHIP_E_NO_RCCL and HIPBodies::bindDevice must say so once
+    and carry on with the in-process peer-copy exchange instead of exiting."""
+    import subprocess
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r); import murbhip, numpy as np, ctypes as C\n"
+            "h = C.c_void_p(); arr = (C.c_int * 2)(0, 0)\n"
+            "assert murbhip.lib().murbhip_create_sharded(C.byref(h), 4096, 2e8, 6.67384e-11, 2, arr, 1) == -2003\n"   # MURBHIP_E_NO_RCCL
+            "with murbhip.HostSim(9000, 'galaxy', devices=(0, 0), exchange='rccl') as two, murbhip.HostSim(9000, 'galaxy') as one:\n"
+            "    two.step(3); one.step(3)\n"
+            "    a, b = two.state(), one.state()\n"
+            "    scale = max(np.abs(b[k]).max() for k in ('qx', 'qy', 'qz'))\n"
+            "    assert all(np.abs(a[k] - b[k]).max() <= 2e-6 * scale for k in ('qx', 'qy', 'qz'))\n"
+            "print('ok')\n") % os.path.join(ROOT, "nbody-eurohpc_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, MURBHIP_RCCL_LIBRARY="none"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout, r.stderr[-1500:])
+    assert "librccl could not be loaded" in r.stderr
 
 
 def test_bench_contract(gpu):
