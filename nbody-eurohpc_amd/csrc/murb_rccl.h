@@ -57,8 +57,8 @@ Rccl& rccl()
     r.GroupStart = (int (*)())dlsym(r.lib, "ncclGroupStart");
     r.GroupEnd = (int (*)())dlsym(r.lib, "ncclGroupEnd");
     r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
-    r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllGather && r.ReduceScatter && r.GroupStart &&
-           r.GroupEnd;
+    // ncclGroupStart/End are bound but not needed: every communicator is driven by a thread of its own (ShardCrew)
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllGather && r.ReduceScatter;
     return r;
 }
 

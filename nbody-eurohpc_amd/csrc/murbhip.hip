@@ -15,17 +15,27 @@
 //     evaluated by exactly one rank, ONE reduce-scatter returns each rank the accelerations of its own
 //     bodies, ONE in-place all-gather publishes the integrated slice; both run on a second,
 //     high-priority stream (RCCL, bound lazily with dlopen, or peer copies/peer reads inside one
-//     process) under the two halves of the own-slice triangle (enqueue_iteration_sym_multi).
+//     process) under the two halves of the own-slice triangle (shard_iteration_sym_multi);
+//   * one process driving several GPUs (murbhip_create_sharded, `--im hip+tile+multi`): the caller stays single-threaded
+//     (reference contract, main.cpp:348-354), but every shard has a host thread of its own inside this library
+//     (ShardCrew) that enqueues its device's share of a step — 100-140 us of HIP calls per shard and step, which one
+//     thread would serialise to more than the 0.9 ms a rank of 8 computes at N = 200 000
+//     (profiles/r03_host_enqueue.txt).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/murbhip.h"
@@ -100,13 +110,32 @@ struct Shard {
     size_t sym_bytes = 0;        // device bytes of all of the above
     hipEvent_t ev_rowsum = nullptr, ev_reduced = nullptr;
     rccl_comm_t comm_rccl = nullptr;
-    std::vector<hipEvent_t> prof;   // start/stop pairs around force launches
+    std::vector<hipEvent_t> prof;   // pool of timing events ("profile"): two per recorded span
     size_t prof_used = 0;
+    std::vector<int> prof_kind;     // what span k (events 2k, 2k+1) brackets: ProfKind
     size_t bytes = 0;
 };
 
 constexpr int kMaxParts = 64;          // rows of the partial-sum buffer
-constexpr size_t kProfPairs = 2048;
+constexpr size_t kProfPairs = 4096;
+
+// What a pair of timing events brackets.  "profile" 1: the force launches only (two event records per launch);
+// 2: also the collectives on the exchange stream, the compute stream's waits for them (= the EXPOSED part of the
+// exchange) and the compute stream's whole step.
+enum ProfKind {
+    kProfForce = 0,       // a force launch outside the exchange pipeline (one GPU; the one-sided kernels)
+    kProfTri1,            // exchange pipeline: first part of the own-slice triangle (runs under the position gather)
+    kProfRect,            // ... rectangles against the other slices
+    kProfTri2,            // ... rest of the own-slice triangle (runs under the reduce-scatter)
+    kProfReduceScatter,   // exchange stream: from "my send chunks are ready" to "my reduced share has arrived"
+    kProfAllGather,       // exchange stream: from "my slice is integrated" to "all slices have arrived"
+    kProfWaitGather,      // compute stream: idle in front of the rectangles, waiting for the gathered positions
+    kProfWaitReduce,      // compute stream: idle in front of the state update, waiting for the reduced share
+    kProfStep,            // compute stream: first launch of a step to the end of its state update
+    kProfKinds
+};
+
+class ShardCrew;
 
 }  // namespace
 
@@ -119,6 +148,7 @@ struct murbhip_ctx {
     int exchange = 0;          // 0 peer copies, 1 RCCL
     bool rank_mode = false;    // one shard here, the others live in other processes
     std::vector<Shard> shards;
+    ShardCrew* crew = nullptr; // one host thread per shard when this process drives several
     int cur = 0;               // record buffer holding the current positions
     bool uploaded = false;
     bool gather_pending = false;   // an exchange into rec[cur] is in flight on the comm streams
@@ -358,26 +388,149 @@ Plan make_plan(const murbhip_ctx* c)
     return p;
 }
 
-int prof_begin(murbhip_ctx* c, Shard& sh)
+// ---- the shards' host threads ------------------------------------------------------------------------------------------
+// The reference drives its simulation from ONE host thread (main.cpp:348-354) and so does every caller of this library.
+// A context with several shards nevertheless enqueues a step from one thread PER SHARD: each shard's share of a step is
+// ~25 HIP calls (5 launches, 2 collectives or W peer copies, the events between them), measured at 100-140 us per shard
+// and step when one thread issues them for 8 shards in turn — 0.8-1.1 ms of host time per step against 0.9 ms of GPU
+// work per rank at N = 200 000 (profiles/r03_host_enqueue.txt), and the collectives cannot complete before the LAST
+// shard's call has been issued.  run() hands every thread the same job and returns when all have finished enqueueing
+// (never waits for the GPU); meet() is a barrier among the threads, needed only where a shard's stream has to wait for an
+// event another shard's thread records (peer-copy exchange).  With one shard there is no thread: the caller runs the job.
+class ShardCrew {
+public:
+    explicit ShardCrew(murbhip_ctx* c) : c_(c), n_((int)c->shards.size())
+    {
+        if (n_ < 2) return;
+        rc_.assign((size_t)n_, 0);
+        for (int i = 0; i < n_; ++i) threads_.emplace_back([this, i] { work(i); });
+    }
+    ~ShardCrew()
+    {
+        if (threads_.empty()) return;
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++generation_; }
+        cv_work_.notify_all();
+        for (std::thread& t : threads_) t.join();
+    }
+    ShardCrew(const ShardCrew&) = delete;
+    ShardCrew& operator=(const ShardCrew&) = delete;
+
+    // job(shard) on every shard's thread; first failure (in shard order) or 0
+    int run(const std::function<int(Shard&)>& job)
+    {
+        if (threads_.empty()) {
+            Shard& sh = c_->shards[0];
+            const int rc = hip_rc(hipSetDevice(sh.device));
+            return rc ? rc : job(sh);
+        }
+        job_ = &job;
+        remaining_.store(n_, std::memory_order_relaxed);
+        { std::lock_guard<std::mutex> lk(m_); ++generation_; }
+        cv_work_.notify_all();
+        for (int spins = 0; remaining_.load(std::memory_order_acquire) != 0;) {   // enqueueing takes ~100 us: spin first
+            if (++spins < 20000) relax();
+            else {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_done_.wait(lk, [this] { return remaining_.load(std::memory_order_acquire) == 0; });
+            }
+        }
+        job_ = nullptr;
+        for (int rc : rc_) if (rc != 0) return rc;
+        return 0;
+    }
+
+    // barrier among the shard threads (call it from inside a job, from EVERY shard's job, failed or not)
+    void meet()
+    {
+        if (threads_.empty()) return;
+        const unsigned my = phase_.load(std::memory_order_acquire);
+        if (arrived_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) {
+            arrived_.store(0, std::memory_order_relaxed);
+            phase_.fetch_add(1, std::memory_order_release);
+            return;
+        }
+        for (int spins = 0; phase_.load(std::memory_order_acquire) == my;) {
+            if (++spins < 4000) relax(); else std::this_thread::yield();
+        }
+    }
+
+private:
+    static void relax() { __builtin_ia32_pause(); }
+    void work(int i)
+    {
+        Shard& sh = c_->shards[(size_t)i];
+        (void)hipSetDevice(sh.device);   // for the life of the thread: no hipSetDevice on the per-step path
+        unsigned long seen = 0;
+        for (;;) {
+            {   // the next job usually follows within microseconds (murbhip_steps): spin briefly, then sleep
+                int spins = 0;
+                while (generation_.load(std::memory_order_acquire) == seen && ++spins < 4000) relax();
+                if (generation_.load(std::memory_order_acquire) == seen) {
+                    std::unique_lock<std::mutex> lk(m_);
+                    cv_work_.wait(lk, [&] { return generation_.load(std::memory_order_acquire) != seen; });
+                }
+            }
+            seen = generation_.load(std::memory_order_acquire);
+            if (stop_) return;
+            rc_[(size_t)i] = (*job_)(sh);
+            if (remaining_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                std::lock_guard<std::mutex> lk(m_);
+                cv_done_.notify_one();
+            }
+        }
+    }
+
+    murbhip_ctx* c_;
+    int n_;
+    std::vector<std::thread> threads_;
+    std::vector<int> rc_;
+    const std::function<int(Shard&)>* job_ = nullptr;
+    std::mutex m_;
+    std::condition_variable cv_work_, cv_done_;
+    std::atomic<unsigned long> generation_{0};
+    std::atomic<int> remaining_{0};
+    std::atomic<int> arrived_{0};
+    std::atomic<unsigned> phase_{0};
+    bool stop_ = false;
+};
+
+// ---- timing spans ("profile") --------------------------------------------------------------------------------------------
+// A span = two events recorded on `stream` around something; -1 = not recording (profiling off, level too low, pool empty:
+// sampling just stops).  Each shard's spans are recorded by that shard's thread only.
+int span_begin(murbhip_ctx* c, Shard& sh, int kind, hipStream_t stream, int* rc)
 {
-    if (!c->profile) return 0;
-    if (sh.prof_used + 2 > sh.prof.size()) return 0;   // pool exhausted: stop sampling, keep running
-    return hip_rc(hipEventRecord(sh.prof[sh.prof_used], sh.compute));
-}
-int prof_end(murbhip_ctx* c, Shard& sh)
-{
-    if (!c->profile) return 0;
-    if (sh.prof_used + 2 > sh.prof.size()) return 0;
-    const int rc = hip_rc(hipEventRecord(sh.prof[sh.prof_used + 1], sh.compute));
+    const int level = (kind <= kProfTri2) ? 1 : 2;
+    if (c->profile < level || sh.prof_used + 2 > sh.prof.size()) return -1;
+    const int k = (int)(sh.prof_used / 2);
     sh.prof_used += 2;
-    return rc;
+    sh.prof_kind[(size_t)k] = kind;
+    const int r = hip_rc(hipEventRecord(sh.prof[(size_t)2 * k], stream));
+    if (r && !*rc) *rc = r;
+    return k;
+}
+int span_end(Shard& sh, int span, hipStream_t stream)
+{
+    if (span < 0) return 0;
+    return hip_rc(hipEventRecord(sh.prof[(size_t)2 * span + 1], stream));
+}
+// hipStreamWaitEvent as a span: the time the stream actually sat waiting (the exposed part of what it waits for)
+int timed_wait(murbhip_ctx* c, Shard& sh, int kind, hipStream_t stream, hipEvent_t ev)
+{
+    int rc = 0;
+    const int sp = span_begin(c, sh, kind, stream, &rc);
+    RC_TRY(rc);
+    HIP_TRY(hipStreamWaitEvent(stream, ev, 0));
+    return span_end(sh, sp, stream);
 }
 
 int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p);
 int ensure_accp(murbhip_ctx* c, Shard& sh);
 int enqueue_sym_passes(murbhip_ctx* c, Shard& sh, bool potential);
 int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_rows = false,
-                       hipStream_t stream = nullptr, bool potential = false, size_t comp_stride = 0);
+                       hipStream_t stream = nullptr, bool potential = false, size_t comp_stride = 0, int kind = kProfForce);
+
+// a fact for murbhip_get_info, noted by the first shard's thread only
+inline void note_interactions(murbhip_ctx* c, const Shard& sh, double v) { if (&sh == &c->shards[0]) c->interactions_per_launch = v; }
 
 // Force over the tiles of `which` (0 = own slice / everything when world == 1, 1 = all but own slice).
 int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
@@ -406,26 +559,30 @@ int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
         RC_TRY(build_sym_schedule(c, sh, p));
         if (sh.sym_main.passes.size() > 1) {
             RC_TRY(enqueue_sym_passes(c, sh, false));
-            c->interactions_per_launch = (double)c->n * (double)c->n / (double)sh.sym_main.passes.size();
+            note_interactions(c, sh, (double)c->n * (double)c->n / (double)sh.sym_main.passes.size());
             return 0;
         }
         RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_total));   // its row sum is fused into the integrate launch
-        c->interactions_per_launch = (double)c->n * (double)c->n;
+        note_interactions(c, sh, (double)c->n * (double)c->n);
         return 0;
     }
     if (p.persistent) {
         const MurbSchedule& sc = p.sched[which];
         if (sc.nblocks <= 0 || a.tiles.count <= 0) return 0;
-        RC_TRY(prof_begin(c, sh));
+        int rc = 0;
+        const int sp = span_begin(c, sh, kProfForce, sh.compute, &rc);
+        RC_TRY(rc);
         RC_TRY(launch_persistent(a, sc, sh.compute));
-        RC_TRY(prof_end(c, sh));
+        RC_TRY(span_end(sh, sp, sh.compute));
     } else {
         if (a.nchunks <= 0 || a.tiles.count <= 0) return 0;
-        RC_TRY(prof_begin(c, sh));
+        int rc = 0;
+        const int sp = span_begin(c, sh, kProfForce, sh.compute, &rc);
+        RC_TRY(rc);
         RC_TRY(launch_force(p.variant, a, i_slots, sh.compute));
-        RC_TRY(prof_end(c, sh));
+        RC_TRY(span_end(sh, sp, sh.compute));
     }
-    c->interactions_per_launch = (double)i_slots * (double)a.tiles.count * MURB_TILE_BODIES;
+    note_interactions(c, sh, (double)i_slots * (double)a.tiles.count * MURB_TILE_BODIES);
     return 0;
 }
 
@@ -471,58 +628,47 @@ int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int updat
     return hip_rc(hipGetLastError());
 }
 
-// Publish every shard's freshly integrated slice of rec[buf] to all shards (comm streams).
-int enqueue_exchange(murbhip_ctx* c, int buf)
+// Publish this shard's freshly integrated slice of rec[buf] to all shards and collect theirs (exchange stream).  Runs on
+// the shard's own thread; every shard's job calls it (it contains a meet()).  `failed`: an earlier phase of this shard's
+// job failed — keep meeting the others, enqueue nothing.
+int shard_exchange(murbhip_ctx* c, Shard& sh, int buf, int failed)
 {
     const size_t slice_f4 = c->slice;                  // float4 records per slice (1 per body slot)
     const size_t slice_bytes = slice_f4 * sizeof(float4);
-    for (Shard& sh : c->shards) {
-        if (is_idle(c, sh)) continue;
-        HIP_TRY(hipSetDevice(sh.device));
-        HIP_TRY(hipEventRecord(sh.ev_integrated, sh.compute));
-    }
+    const bool idle = is_idle(c, sh);
+    int rc = failed;
+    if (!rc && !idle) rc = hip_rc(hipEventRecord(sh.ev_integrated, sh.compute));
+    if (c->exchange == 0) c->crew->meet();             // the peers' ev_integrated are recorded
+    if (rc) return rc;
+    int span = -1;
     if (c->exchange == 1) {
-        Rccl& r = rccl();
-        for (Shard& sh : c->shards) {
-            HIP_TRY(hipSetDevice(sh.device));
-            HIP_TRY(hipStreamWaitEvent(sh.comm, sh.ev_integrated, 0));
-        }
-        RC_TRY(nccl_rc(r.GroupStart()));
-        for (Shard& sh : c->shards) {
-            HIP_TRY(hipSetDevice(sh.device));
-            float4* base = sh.rec[buf];
-            RC_TRY(nccl_rc(r.AllGather(base + (size_t)sh.rank * slice_f4, base, slice_f4 * 4, kRcclFloat, sh.comm_rccl,
-                                       sh.comm)));
-        }
-        RC_TRY(nccl_rc(r.GroupEnd()));
+        // one communicator per shard, each driven by its own thread: no ncclGroupStart/End around the calls
+        HIP_TRY(hipStreamWaitEvent(sh.comm, sh.ev_integrated, 0));
+        span = span_begin(c, sh, kProfAllGather, sh.comm, &rc);
+        RC_TRY(rc);
+        float4* base = sh.rec[buf];
+        RC_TRY(nccl_rc(rccl().AllGather(base + (size_t)sh.rank * slice_f4, base, slice_f4 * 4, kRcclFloat, sh.comm_rccl, sh.comm)));
     } else {
+        if (idle) return 0;
         // pull model: each shard copies every peer's slice out of the peer's buffer
-        for (Shard& sh : c->shards) {
-            if (is_idle(c, sh)) continue;
-            HIP_TRY(hipSetDevice(sh.device));
-            for (Shard& peer : c->shards) {
-                if (&peer == &sh) continue;
-                HIP_TRY(hipStreamWaitEvent(sh.comm, peer.ev_integrated, 0));
-            }
-            HIP_TRY(hipStreamWaitEvent(sh.comm, sh.ev_integrated, 0));
-            for (Shard& peer : c->shards) {
-                if (&peer == &sh) continue;
-                const size_t off = (size_t)peer.rank * slice_f4;
-                if (peer.device == sh.device)
-                    HIP_TRY(hipMemcpyAsync(sh.rec[buf] + off, peer.rec[buf] + off, slice_bytes, hipMemcpyDeviceToDevice,
-                                           sh.comm));
-                else
-                    HIP_TRY(hipMemcpyPeerAsync(sh.rec[buf] + off, sh.device, peer.rec[buf] + off, peer.device, slice_bytes,
-                                               sh.comm));
-            }
+        for (Shard& peer : c->shards) {
+            if (&peer == &sh || is_idle(c, peer)) continue;
+            HIP_TRY(hipStreamWaitEvent(sh.comm, peer.ev_integrated, 0));
+        }
+        HIP_TRY(hipStreamWaitEvent(sh.comm, sh.ev_integrated, 0));
+        span = span_begin(c, sh, kProfAllGather, sh.comm, &rc);
+        RC_TRY(rc);
+        for (Shard& peer : c->shards) {
+            if (&peer == &sh) continue;
+            const size_t off = (size_t)peer.rank * slice_f4;
+            if (peer.device == sh.device)
+                HIP_TRY(hipMemcpyAsync(sh.rec[buf] + off, peer.rec[buf] + off, slice_bytes, hipMemcpyDeviceToDevice, sh.comm));
+            else
+                HIP_TRY(hipMemcpyPeerAsync(sh.rec[buf] + off, sh.device, peer.rec[buf] + off, peer.device, slice_bytes, sh.comm));
         }
     }
-    for (Shard& sh : c->shards) {
-        if (is_idle(c, sh)) continue;
-        HIP_TRY(hipSetDevice(sh.device));
-        HIP_TRY(hipEventRecord(sh.ev_gathered, sh.comm));
-    }
-    c->gather_pending = true;
+    RC_TRY(span_end(sh, span, sh.comm));
+    if (!idle) HIP_TRY(hipEventRecord(sh.ev_gathered, sh.comm));
     return 0;
 }
 
@@ -686,18 +832,22 @@ void plan_sym_layout(int W, int r, int tb, int split, int waves, int taper, bool
 // unordered body pair is evaluated by exactly one rank.  A rank's partial sums for ALL slices it
 // touched are then row-summed into one chunk per slice and combined with ONE reduce-scatter (each
 // rank receives the complete accelerations of its own bodies); positions travel as before.
+// false when the shard's tables were built for exactly this plan and these options.  A rebuild of EXISTING tables needs
+// every shard of the process drained first (the peer-read sums of the previous step may still be reading this shard's
+// send buffer): enqueue_iteration and murbhip_energy do that on the caller's thread before the shards' threads start.
+bool sym_schedule_stale(const murbhip_ctx* c, const Shard& sh, const Plan& p)
+{
+    const bool exchange_mode = c->world > 1 || c->force_exchange;
+    return !(sh.sym_items && sh.sym_split == p.split && sh.sym_waves == p.waves && sh.sym_taper == p.taper && sh.sym_diag_tri == (int)p.diag_tri &&
+             sh.sym_exchange_mode == exchange_mode && sh.sym_xcd_order == c->xcd_order && sh.sym_pass_mb == c->sym_pass_mb &&
+             (!exchange_mode || (sh.sym_tri_first == c->tri_first_pct && sh.sym_overlap == c->overlap)));
+}
+
 int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
 {
     const bool exchange_mode = c->world > 1 || c->force_exchange;
     sh.sym_red = p.red;
-    if (sh.sym_items && sh.sym_split == p.split && sh.sym_waves == p.waves && sh.sym_taper == p.taper && sh.sym_diag_tri == (int)p.diag_tri &&
-        sh.sym_exchange_mode == exchange_mode && sh.sym_xcd_order == c->xcd_order && sh.sym_pass_mb == c->sym_pass_mb &&
-        (!exchange_mode || (sh.sym_tri_first == c->tri_first_pct && sh.sym_overlap == c->overlap)))
-        return 0;
-    if (sh.sym_items) {   // option changed: rebuild.  Everything in flight first — also on the other shards of this process,
-        RC_TRY(murbhip_sync(c));   // whose peer-read sums of the previous step may still be reading our send buffer
-        HIP_TRY(hipSetDevice(sh.device));
-    }
+    if (!sym_schedule_stale(c, sh, p)) return 0;
     hipFree(sh.sym_items); sh.sym_items = nullptr;
     free_sym_set(sh.sym_main);
     free_sym_set(sh.sym_tri);
@@ -752,7 +902,7 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
 }
 
 int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_rows, hipStream_t stream,
-                       bool potential, size_t comp_stride)
+                       bool potential, size_t comp_stride, int kind)
 {
     if (count <= 0) return 0;
     if (!stream) stream = sh.compute;
@@ -765,7 +915,9 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
     sa.item_first = first;
     sa.soft2 = c->soft2;
     const bool timed = stream == sh.compute && !potential;   // the profiling events live on the main compute stream
-    if (timed) RC_TRY(prof_begin(c, sh));
+    int rc_span = 0;
+    const int sp = timed ? span_begin(c, sh, kind, stream, &rc_span) : -1;
+    RC_TRY(rc_span);
     const dim3 grid((unsigned)count);
     if (sh.sym_waves == 8) {
         if (potential) hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1, 1>), grid, dim3(512), 0, stream, sa);
@@ -777,7 +929,7 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
         else hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1>), grid, dim3(256), 0, stream, sa);
     }
     RC_TRY(hip_rc(hipGetLastError()));
-    if (timed) RC_TRY(prof_end(c, sh));
+    RC_TRY(span_end(sh, sp, stream));
     return 0;
 }
 
@@ -790,25 +942,72 @@ int enqueue_sym_rowsum(const SymSet& st, float* out, unsigned int out_slice_slot
     return hip_rc(hipGetLastError());
 }
 
-// One iteration under the half-ring schedule.  Per shard, on the compute stream unless noted:
+// The reduce-scatter of the send chunks on the exchange stream: every rank ends up with the other ranks' (and its own
+// rectangles') contributions to its own bodies in sym_recv.  Called by every shard's thread after its row sum has been
+// enqueued (ev_rowsum recorded; with peer copies: after the meet() that follows).
+int shard_reduce_scatter(murbhip_ctx* c, Shard& sh)
+{
+    const unsigned int chunk_floats = (unsigned int)(3 * c->slice);
+    const bool idle = is_idle(c, sh);
+    int rc = 0, span = -1;
+    if (c->exchange == 1) {
+        HIP_TRY(hipStreamWaitEvent(sh.comm, sh.ev_rowsum, 0));
+        span = span_begin(c, sh, kProfReduceScatter, sh.comm, &rc);
+        RC_TRY(rc);
+        RC_TRY(nccl_rc(rccl().ReduceScatter(sh.sym_send, sh.sym_recv, chunk_floats, kRcclFloat, kRcclSum, sh.comm_rccl, sh.comm)));
+    } else {
+        if (idle) return 0;
+        MurbPeerPtrs peers{};
+        peers.n = (int)c->shards.size();
+        for (size_t k = 0; k < c->shards.size(); ++k) peers.p[c->shards[k].rank] = c->shards[k].sym_send;
+        for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.comm, peer.ev_rowsum, 0));
+        span = span_begin(c, sh, kProfReduceScatter, sh.comm, &rc);
+        RC_TRY(rc);
+        hipLaunchKernelGGL(murb_sym_peer_sum_kernel, dim3((chunk_floats + 255) / 256), dim3(256), 0, sh.comm, peers,
+                           (unsigned long)sh.rank * chunk_floats, chunk_floats, sh.sym_recv);
+        RC_TRY(hip_rc(hipGetLastError()));
+    }
+    RC_TRY(span_end(sh, span, sh.comm));
+    if (!idle) HIP_TRY(hipEventRecord(sh.ev_reduced, sh.comm));
+    return 0;
+}
+
+// nobody may still be reading our send buffer: the peer-read sums of the previous step (one process), or our own
+// previous reduce-scatter (RCCL reads it on the exchange stream)
+int wait_send_buffer_free(murbhip_ctx* c, Shard& sh)
+{
+    if (!c->reduce_pending) return 0;
+    if (c->exchange == 0) { for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.compute, peer.ev_reduced, 0)); }
+    else HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
+    return 0;
+}
+
+// One iteration under the half-ring schedule: ONE shard's share, enqueued by that shard's own thread (ShardCrew).  On the
+// compute stream unless noted:
 //   T1  first part of the own-slice triangle          (needs no remote data: overlaps the position gather)
 //       wait: positions of the previous step gathered
 //   R   rectangles against the other slices            -> the rectangles' rows (sym_main)
 //   SR  row sum of those rows -> send chunks           (own-slice chunk = i-side sums of the rectangles)
-//       [comm stream] reduce-scatter of the chunks -> recv          (overlaps T2)
+//       [exchange stream] reduce-scatter of the chunks -> recv          (overlaps T2)
 //   T2  rest of the own-slice triangle                 -> the triangle's rows (sym_tri)
 //       wait: reduce-scatter done
-//   I   row sum of the triangle's rows + recv, state update: one launch ; then [comm stream] all-gather of the new positions
+//   I   row sum of the triangle's rows + recv, state update: one launch ; then [exchange stream] all-gather of the new positions
 // The triangle never enters the reduce-scatter (it only touches the rank's own bodies), which is what
 // lets half of it hide the collective's latency.
-int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int update_state)
+// The context's fields (cur, gather_pending, ...) are read-only while the shards' threads run; the caller updates them
+// afterwards.  meet() only where a stream must wait for an event ANOTHER shard's thread records (peer-copy exchange): the
+// shards otherwise never wait for each other on the host.
+int shard_iteration_sym_multi(murbhip_ctx* c, Shard& sh, const Plan& p, float dt, int update_state)
 {
-    const unsigned int chunk_floats = (unsigned int)(3 * c->slice);
-    for (Shard& sh : c->shards) {
-        HIP_TRY(hipSetDevice(sh.device));
-        RC_TRY(build_sym_schedule(c, sh, p));
-        if (is_idle(c, sh)) continue;   // "solo_shard" timing aid: idle shards enqueue nothing at all
-        const int own = sh.sym_items_own, t1 = sh.sym_t1;
+    const bool idle = is_idle(c, sh);   // "solo_shard" timing aid: idle shards enqueue no work of their own
+    const bool copies = c->exchange == 0;
+    int rc = build_sym_schedule(c, sh, p);
+    const int own = sh.sym_items_own, t1 = sh.sym_t1;
+    int step_span = -1;
+    if (!rc && !idle) rc = [&]() -> int {
+        int r = 0;
+        step_span = span_begin(c, sh, kProfStep, sh.compute, &r);
+        RC_TRY(r);
         if (c->overlap == 2) {
             // the whole own-slice triangle on a second, lowest-priority compute stream: it runs alone while
             // the positions are still being gathered, then fills the gaps and the tail of the rectangles
@@ -817,59 +1016,25 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
             RC_TRY(enqueue_sym_rowsum(sh.sym_tri, sh.sym_tri_acc, (unsigned int)c->slice, sh.compute_low));
             HIP_TRY(hipEventRecord(sh.ev_tri, sh.compute_low));
         }
-        RC_TRY(enqueue_sym_launch(c, sh, 0, t1, true));
-        if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
-        RC_TRY(enqueue_sym_launch(c, sh, own, sh.sym_items_total - own, false));
-        // nobody may still be reading our send buffer: the peer-read sums of the previous step (one process), or our
-        // own previous reduce-scatter (RCCL reads it on the comm stream)
-        if (c->reduce_pending) {
-            if (c->exchange == 0) for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.compute, peer.ev_reduced, 0));
-            else HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
-        }
+        RC_TRY(enqueue_sym_launch(c, sh, 0, t1, true, nullptr, false, 0, kProfTri1));
+        if (c->gather_pending) RC_TRY(timed_wait(c, sh, kProfWaitGather, sh.compute, sh.ev_gathered));
+        RC_TRY(enqueue_sym_launch(c, sh, own, sh.sym_items_total - own, false, nullptr, false, 0, kProfRect));
+        RC_TRY(wait_send_buffer_free(c, sh));
         RC_TRY(enqueue_sym_rowsum(sh.sym_main, sh.sym_send, (unsigned int)c->slice, sh.compute));
         HIP_TRY(hipEventRecord(sh.ev_rowsum, sh.compute));
-        c->interactions_per_launch = (double)sh.count * (double)c->n;
-    }
-    // reduce-scatter on the comm streams: every rank ends up with the other ranks' (and its own
-    // rectangles') contributions to its own bodies
-    if (c->exchange == 1) {
-        Rccl& r = rccl();
-        for (Shard& sh : c->shards) {
-            HIP_TRY(hipSetDevice(sh.device));
-            HIP_TRY(hipStreamWaitEvent(sh.comm, sh.ev_rowsum, 0));
-        }
-        RC_TRY(nccl_rc(r.GroupStart()));
-        for (Shard& sh : c->shards) {
-            HIP_TRY(hipSetDevice(sh.device));
-            RC_TRY(nccl_rc(r.ReduceScatter(sh.sym_send, sh.sym_recv, chunk_floats, kRcclFloat, kRcclSum, sh.comm_rccl,
-                                           sh.comm)));
-        }
-        RC_TRY(nccl_rc(r.GroupEnd()));
-    } else {
-        MurbPeerPtrs peers{};
-        peers.n = (int)c->shards.size();
-        for (size_t k = 0; k < c->shards.size(); ++k) peers.p[c->shards[k].rank] = c->shards[k].sym_send;
-        for (Shard& sh : c->shards) {
-            if (is_idle(c, sh)) continue;
-            HIP_TRY(hipSetDevice(sh.device));
-            for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.comm, peer.ev_rowsum, 0));
-            hipLaunchKernelGGL(murb_sym_peer_sum_kernel, dim3((chunk_floats + 255) / 256), dim3(256), 0, sh.comm, peers,
-                               (unsigned long)sh.rank * chunk_floats, chunk_floats, sh.sym_recv);
-            RC_TRY(hip_rc(hipGetLastError()));
-        }
-    }
-    for (Shard& sh : c->shards) {
-        if (is_idle(c, sh)) continue;
-        HIP_TRY(hipSetDevice(sh.device));
-        HIP_TRY(hipEventRecord(sh.ev_reduced, sh.comm));
+        note_interactions(c, sh, (double)sh.count * (double)c->n);
+        return 0;
+    }();
+    if (copies) c->crew->meet();   // every shard's ev_rowsum is recorded
+    if (!rc) rc = shard_reduce_scatter(c, sh);
+    if (!rc && !idle) rc = [&]() -> int {
         // meanwhile: the rest of the own-slice triangle and its row sum
-        const int own = sh.sym_items_own, t1 = sh.sym_t1;
         if (c->overlap == 2) {
             HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_tri, 0));
         } else {
-            RC_TRY(enqueue_sym_launch(c, sh, t1, own - t1, true));
+            RC_TRY(enqueue_sym_launch(c, sh, t1, own - t1, true, nullptr, false, 0, kProfTri2));
         }
-        HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
+        RC_TRY(timed_wait(c, sh, kProfWaitReduce, sh.compute, sh.ev_reduced));
         MurbIntegrateArgs a{};
         a.rec_in = sh.rec[c->cur];
         a.rec_out = sh.rec[c->cur ^ 1];
@@ -892,14 +1057,12 @@ int enqueue_iteration_sym_multi(murbhip_ctx* c, const Plan& p, float dt, int upd
                                sh.sym_tri.part, sh.sym_tri.comp_stride, sh.sym_tri.rows, a);
         }
         RC_TRY(hip_rc(hipGetLastError()));
-        if (!update_state) HIP_TRY(hipEventRecord(sh.ev_integrated, sh.compute));   // else enqueue_exchange records it
-    }
-    c->reduce_pending = true;
-    if (update_state) {
-        RC_TRY(enqueue_exchange(c, c->cur ^ 1));
-        c->cur ^= 1;
-    }
-    return 0;
+        RC_TRY(span_end(sh, step_span, sh.compute));
+        if (!update_state) HIP_TRY(hipEventRecord(sh.ev_integrated, sh.compute));   // else shard_exchange records it
+        return 0;
+    }();
+    if (update_state) rc = shard_exchange(c, sh, c->cur ^ 1, rc);
+    return rc;
 }
 
 // One GPU, several passes: every pass's items into the shared row buffer, its row sums added to the fp64 accumulator.
@@ -918,71 +1081,62 @@ int enqueue_sym_passes(murbhip_ctx* c, Shard& sh, bool potential)
 // The potential sweep of murbhip_energy under the half-ring schedule: the same items as a force evaluation in the
 // kernel's PHI form (phi_i += G m_j / r and phi_j += G m_i / r per pair, once), the same reduce-scatter — half the
 // pair terms of a one-sided sweep per rank.  No overlap games here: triangle, rectangles, row sums, reduce-scatter,
-// phi = received + own triangle.  A collective in one-process-per-GPU mode, like a step.
-int enqueue_potential_sym_multi(murbhip_ctx* c, const Plan& p)
+// phi = received + own triangle.  A collective in one-process-per-GPU mode, like a step.  One shard's share, on its thread.
+int shard_potential_sym_multi(murbhip_ctx* c, Shard& sh, const Plan& p)
 {
-    const unsigned int chunk_floats = (unsigned int)(3 * c->slice);
-    for (Shard& sh : c->shards) {
-        HIP_TRY(hipSetDevice(sh.device));
-        RC_TRY(build_sym_schedule(c, sh, p));
-        if (is_idle(c, sh)) continue;
+    const bool idle = is_idle(c, sh);
+    int rc = build_sym_schedule(c, sh, p);
+    if (!rc && !idle) rc = [&]() -> int {
         if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
         RC_TRY(enqueue_sym_launch(c, sh, 0, sh.sym_items_own, true, nullptr, true));
         RC_TRY(enqueue_sym_launch(c, sh, sh.sym_items_own, sh.sym_items_total - sh.sym_items_own, false, nullptr, true));
         RC_TRY(enqueue_sym_rowsum(sh.sym_tri, sh.sym_tri_acc, (unsigned int)c->slice, sh.compute));
-        if (c->reduce_pending) {   // see enqueue_iteration_sym_multi: nobody may still be reading our send buffer
-            if (c->exchange == 0) for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.compute, peer.ev_reduced, 0));
-            else HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
-        }
+        RC_TRY(wait_send_buffer_free(c, sh));
         RC_TRY(enqueue_sym_rowsum(sh.sym_main, sh.sym_send, (unsigned int)c->slice, sh.compute));
         HIP_TRY(hipEventRecord(sh.ev_rowsum, sh.compute));
-    }
-    if (c->exchange == 1) {
-        Rccl& r = rccl();
-        for (Shard& sh : c->shards) {
-            HIP_TRY(hipSetDevice(sh.device));
-            HIP_TRY(hipStreamWaitEvent(sh.comm, sh.ev_rowsum, 0));
+        return 0;
+    }();
+    if (c->exchange == 0) c->crew->meet();
+    if (!rc) rc = shard_reduce_scatter(c, sh);
+    if (rc || idle) return rc;
+    HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
+    MurbIntegrateArgs a{};   // no state update: phi_out = received + own triangle (component 0 is the potential)
+    a.rec_in = sh.rec[c->cur];
+    a.rec_out = sh.rec[c->cur ^ 1];
+    a.vel = sh.vel;
+    a.acc_out = sh.phi_out;
+    a.acc_planes = sh.sym_recv;
+    a.acc_planes2 = sh.sym_tri_acc;
+    a.i_first_slot = (int)((unsigned long)sh.rank * c->slice);
+    a.count = (int)sh.count;
+    a.acc_stride = (unsigned int)c->slice;
+    a.update_state = 0;
+    hipLaunchKernelGGL(murb_integrate_kernel, dim3((unsigned)((c->slice / 2 + 255) / 256)), dim3(256), 0, sh.compute, a);
+    return hip_rc(hipGetLastError());
+}
+
+// One iteration with the one-sided kernels (or with one shard and no exchange): one shard's share, on its thread.
+int shard_iteration_plain(murbhip_ctx* c, Shard& sh, const Plan& p, float dt, int update_state, bool reuse)
+{
+    const bool exchange = update_state && (c->world > 1 || c->force_exchange);
+    int rc = 0;
+    if (!is_idle(c, sh)) rc = [&]() -> int {   // timing aid: see "solo_shard"
+        if (c->world == 1) {
+            if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
+            if (!reuse) RC_TRY(enqueue_force(c, sh, p, 0));
+        } else if (c->overlap) {
+            RC_TRY(enqueue_force(c, sh, p, 0));   // own slice: written by our own integrate, already ordered
+            if (c->gather_pending) RC_TRY(timed_wait(c, sh, kProfWaitGather, sh.compute, sh.ev_gathered));
+            RC_TRY(enqueue_force(c, sh, p, 1));
+        } else {
+            if (c->gather_pending) RC_TRY(timed_wait(c, sh, kProfWaitGather, sh.compute, sh.ev_gathered));
+            RC_TRY(enqueue_force(c, sh, p, 0));
+            RC_TRY(enqueue_force(c, sh, p, 1));
         }
-        RC_TRY(nccl_rc(r.GroupStart()));
-        for (Shard& sh : c->shards) {
-            HIP_TRY(hipSetDevice(sh.device));
-            RC_TRY(nccl_rc(r.ReduceScatter(sh.sym_send, sh.sym_recv, chunk_floats, kRcclFloat, kRcclSum, sh.comm_rccl, sh.comm)));
-        }
-        RC_TRY(nccl_rc(r.GroupEnd()));
-    } else {
-        MurbPeerPtrs peers{};
-        peers.n = (int)c->shards.size();
-        for (size_t k = 0; k < c->shards.size(); ++k) peers.p[c->shards[k].rank] = c->shards[k].sym_send;
-        for (Shard& sh : c->shards) {
-            if (is_idle(c, sh)) continue;
-            HIP_TRY(hipSetDevice(sh.device));
-            for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.comm, peer.ev_rowsum, 0));
-            hipLaunchKernelGGL(murb_sym_peer_sum_kernel, dim3((chunk_floats + 255) / 256), dim3(256), 0, sh.comm, peers,
-                               (unsigned long)sh.rank * chunk_floats, chunk_floats, sh.sym_recv);
-            RC_TRY(hip_rc(hipGetLastError()));
-        }
-    }
-    for (Shard& sh : c->shards) {
-        if (is_idle(c, sh)) continue;
-        HIP_TRY(hipSetDevice(sh.device));
-        HIP_TRY(hipEventRecord(sh.ev_reduced, sh.comm));
-        HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
-        MurbIntegrateArgs a{};   // no state update: phi_out = received + own triangle (component 0 is the potential)
-        a.rec_in = sh.rec[c->cur];
-        a.rec_out = sh.rec[c->cur ^ 1];
-        a.vel = sh.vel;
-        a.acc_out = sh.phi_out;
-        a.acc_planes = sh.sym_recv;
-        a.acc_planes2 = sh.sym_tri_acc;
-        a.i_first_slot = (int)((unsigned long)sh.rank * c->slice);
-        a.count = (int)sh.count;
-        a.acc_stride = (unsigned int)c->slice;
-        a.update_state = 0;
-        hipLaunchKernelGGL(murb_integrate_kernel, dim3((unsigned)((c->slice / 2 + 255) / 256)), dim3(256), 0, sh.compute, a);
-        RC_TRY(hip_rc(hipGetLastError()));
-    }
-    c->reduce_pending = true;
-    return 0;
+        return enqueue_integrate(c, sh, p.parts_local + p.parts_remote, dt, update_state, reuse ? nullptr : &p, -1, nullptr, reuse);
+    }();
+    if (exchange) rc = shard_exchange(c, sh, c->cur ^ 1, rc);
+    return rc;
 }
 
 int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
@@ -996,30 +1150,19 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
     c->acc_current = false;
     if (have_acc && !update_state) { c->acc_current = true; return 0; }
     const bool reuse = have_acc && c->world == 1 && !c->force_exchange && c->solo_shard < 0;
-    if (p.symmetric && (c->world > 1 || c->force_exchange)) {
-        RC_TRY(enqueue_iteration_sym_multi(c, p, dt, update_state));
-        c->acc_current = !update_state;
-        return 0;
+    const bool exchanging = c->world > 1 || c->force_exchange;
+    if (p.symmetric) {
+        bool stale = false;
+        for (const Shard& sh : c->shards) stale = stale || (sh.sym_items && sym_schedule_stale(c, sh, p));
+        if (stale) RC_TRY(murbhip_sync(c));   // tables are rebuilt below: nothing may be in flight
     }
-    for (Shard& sh : c->shards) {
-        HIP_TRY(hipSetDevice(sh.device));
-        if (is_idle(c, sh)) continue;   // timing aid: see "solo_shard"
-        if (c->world == 1) {
-            if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
-            if (!reuse) RC_TRY(enqueue_force(c, sh, p, 0));
-        } else if (c->overlap) {
-            RC_TRY(enqueue_force(c, sh, p, 0));   // own slice: written by our own integrate, already ordered
-            if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
-            RC_TRY(enqueue_force(c, sh, p, 1));
-        } else {
-            if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
-            RC_TRY(enqueue_force(c, sh, p, 0));
-            RC_TRY(enqueue_force(c, sh, p, 1));
-        }
-        RC_TRY(enqueue_integrate(c, sh, p.parts_local + p.parts_remote, dt, update_state, reuse ? nullptr : &p, -1, nullptr, reuse));
-    }
+    if (p.symmetric && exchanging)
+        RC_TRY(c->crew->run([&](Shard& sh) { return shard_iteration_sym_multi(c, sh, p, dt, update_state); }));
+    else
+        RC_TRY(c->crew->run([&](Shard& sh) { return shard_iteration_plain(c, sh, p, dt, update_state, reuse); }));
+    if (p.symmetric && exchanging) c->reduce_pending = true;
     if (update_state) {
-        if (c->world > 1 || c->force_exchange) RC_TRY(enqueue_exchange(c, c->cur ^ 1));
+        if (exchanging) c->gather_pending = true;
         c->cur ^= 1;
     } else {
         c->acc_current = true;
@@ -1117,6 +1260,8 @@ int create_common(murbhip_ctx** out, unsigned long n, float soft, float g, int w
                 }
     }
     if (rc != 0) { murbhip_destroy(c); return rc; }
+    c->crew = new (std::nothrow) ShardCrew(c);   // after the shards exist: its threads bind to their devices at once
+    if (!c->crew) { murbhip_destroy(c); return MURBHIP_E_NOMEM; }
     *out = c;
     return 0;
 }
@@ -1314,6 +1459,8 @@ int murbhip_create_rank(murbhip_ctx** out, unsigned long n, float soft, float g,
 int murbhip_destroy(murbhip_ctx* c)
 {
     if (!c) return 0;
+    delete c->crew;   // joins the shards' threads (idle: every entry point returns only when they have finished enqueueing)
+    c->crew = nullptr;
     for (Shard& sh : c->shards) {
         hipSetDevice(sh.device);
         if (sh.compute) hipStreamSynchronize(sh.compute);
@@ -1513,7 +1660,10 @@ int murbhip_integrate_host_acc(murbhip_ctx* c, const float* ax, const float* ay,
         HIP_TRY(hipStreamSynchronize(sh.compute));   // `part` is reused for the next shard
         RC_TRY(enqueue_integrate(c, sh, 1, dt, 1, nullptr, 0));
     }
-    if (c->world > 1) RC_TRY(enqueue_exchange(c, c->cur ^ 1));
+    if (c->world > 1) {
+        RC_TRY(c->crew->run([&](Shard& sh) { return shard_exchange(c, sh, c->cur ^ 1, 0); }));
+        c->gather_pending = true;
+    }
     c->cur ^= 1;
     c->acc_current = false;
     return 0;
@@ -1595,7 +1745,15 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
             sh.bytes += 3 * c->slice * sizeof(float);
         }
     }
-    if (symmetric_multi) RC_TRY(enqueue_potential_sym_multi(c, main_plan));
+    if (main_plan.symmetric) {   // a rebuild of existing tables needs everything drained (see sym_schedule_stale)
+        bool stale = false;
+        for (const Shard& sh : c->shards) stale = stale || (sh.sym_items && sym_schedule_stale(c, sh, main_plan));
+        if (stale) RC_TRY(murbhip_sync(c));
+    }
+    if (symmetric_multi) {
+        RC_TRY(c->crew->run([&](Shard& sh) { return shard_potential_sym_multi(c, sh, main_plan); }));
+        c->reduce_pending = true;
+    }
     for (Shard& sh : c->shards) {
         if (symmetric_multi) break;
         HIP_TRY(hipSetDevice(sh.device));
@@ -1678,11 +1836,14 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
         c->force_exchange = value ? 1 : 0;
     }
     else if (k == "profile") {
-        c->profile = value ? 1 : 0;
+        if (value < 0 || value > 2) return MURBHIP_E_INVALID;
+        RC_TRY(murbhip_sync(c));   // spans of the previous setting may still be in flight
+        c->profile = (int)value;
         for (Shard& sh : c->shards) {
             HIP_TRY(hipSetDevice(sh.device));
             if (c->profile && sh.prof.empty()) {
                 sh.prof.resize(2 * kProfPairs);
+                sh.prof_kind.assign(kProfPairs, 0);
                 for (hipEvent_t& e : sh.prof) HIP_TRY(hipEventCreate(&e));
             }
             sh.prof_used = 0;
@@ -1713,20 +1874,46 @@ int murbhip_get_info(murbhip_ctx* c, const char* key, double* value)
     else if (k == "variant") *value = p.variant;
     else if (k == "interactions_per_launch") *value = c->interactions_per_launch;
     else if (k == "device_bytes") { double b = 0; for (Shard& sh : c->shards) b += (double)sh.bytes; *value = b; }
-    else if (k == "force_launches" || k == "force_ms_avg" || k == "force_ms_total") {
+    else if (k == "spans_dropped") {   // 1: the event pool ran out during the profiled steps (averages cover the first part only)
+        *value = 0;
+        for (Shard& sh : c->shards) if (!sh.prof.empty() && sh.prof_used + 2 > sh.prof.size()) *value = 1;
+    }
+    else if (k == "force_launches" || k == "force_ms_avg" || k == "force_ms_total" || k.rfind("span_", 0) == 0 || k == "compute_wait_ms_per_step") {
+        // Timing spans of the profiled steps ("profile"), over all shards of this process:
+        //   force_*                       every force launch (one GPU: the launch; exchange pipeline: T1, R and T2 together)
+        //   span_<kind>_ms_avg / _count   kind in tri1, rect, tri2, reduce_scatter, all_gather, wait_gather, wait_reduce, step
+        //   compute_wait_ms_per_step      (wait_gather + wait_reduce) per profiled step: what the exchange costs the compute stream
+        static const char* const names[kProfKinds] = {"force", "tri1", "rect", "tri2", "reduce_scatter", "all_gather", "wait_gather",
+                                                      "wait_reduce", "step"};
         RC_TRY(murbhip_sync(c));
-        double total = 0; size_t launches = 0;
+        double total[kProfKinds] = {0};
+        size_t count[kProfKinds] = {0};
         for (Shard& sh : c->shards) {
             HIP_TRY(hipSetDevice(sh.device));
             for (size_t i = 0; i + 1 < sh.prof_used; i += 2) {
                 float ms = 0.f;
                 HIP_TRY(hipEventElapsedTime(&ms, sh.prof[i], sh.prof[i + 1]));
-                total += ms; ++launches;
+                const int kind = sh.prof_kind[i / 2];
+                total[kind] += ms; ++count[kind];
             }
         }
-        if (k == "force_launches") *value = (double)launches;
-        else if (k == "force_ms_total") *value = total;
-        else *value = launches ? total / (double)launches : 0.0;
+        const double f_total = total[kProfForce] + total[kProfTri1] + total[kProfRect] + total[kProfTri2];
+        const size_t f_count = count[kProfForce] + count[kProfTri1] + count[kProfRect] + count[kProfTri2];
+        if (k == "force_launches") *value = (double)f_count;
+        else if (k == "force_ms_total") *value = f_total;
+        else if (k == "force_ms_avg") *value = f_count ? f_total / (double)f_count : 0.0;
+        else if (k == "compute_wait_ms_per_step")
+            *value = count[kProfStep] ? (total[kProfWaitGather] + total[kProfWaitReduce]) / (double)count[kProfStep] : 0.0;
+        else {
+            const bool avg = k.size() > 7 && k.compare(k.size() - 7, 7, "_ms_avg") == 0;
+            const bool cnt = k.size() > 6 && k.compare(k.size() - 6, 6, "_count") == 0;
+            if (!avg && !cnt) return MURBHIP_E_INVALID;
+            const std::string name = k.substr(5, k.size() - 5 - (avg ? 7 : 6));
+            int kind = -1;
+            for (int q = 0; q < kProfKinds; ++q) if (name == names[q]) kind = q;
+            if (kind < 0) return MURBHIP_E_INVALID;
+            *value = avg ? (count[kind] ? total[kind] / (double)count[kind] : 0.0) : (double)count[kind];
+        }
     } else return MURBHIP_E_INVALID;
     return 0;
 }

@@ -17,6 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "_build", "liboracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libmurbref.so")
 REF_AVX2_SO = os.path.join(HERE, "_ref", "libmurbref_avx2.so")   # same sources + -mavx2 -mfma: speed baseline only
+REF_AVX512_SO = os.path.join(HERE, "_ref", "libmurbref_avx512.so")   # ... + the AVX-512 subsets: speed baseline only
+AVX512_FLAGS = ("avx512f", "avx512dq", "avx512bw", "avx512vl")
 
 G = np.float32(6.67384e-11)      # SimulationNBodyInterface.hpp:18
 SOFT = np.float32(2e8)           # main.cpp:47
@@ -171,12 +173,35 @@ def rel_err(test, ref):
 _ref = {}
 
 
-def have_ref(avx2=False):
-    return os.path.exists(REF_AVX2_SO if avx2 else REF_SO)
+def _ref_path(avx2=False, isa=None):
+    isa = isa or ("avx2" if avx2 else None)
+    return {None: REF_SO, "sse2": REF_SO, "avx2": REF_AVX2_SO, "avx512": REF_AVX512_SO}[isa]
 
 
-def ref_lib(avx2=False):
-    path = REF_AVX2_SO if avx2 else REF_SO
+def cpu_has(flags):
+    """True when /proc/cpuinfo lists every one of `flags` (an AVX-512 build must not be loaded on a CPU without them)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                have = set(line.split(":", 1)[1].split())
+                return all(f in have for f in flags)
+    except OSError:
+        pass
+    return False
+
+
+def have_ref(avx2=False, isa=None):
+    """The reference CPU build of that instruction set exists AND this host can run it."""
+    isa = isa or ("avx2" if avx2 else None)
+    if isa == "avx512" and not cpu_has(AVX512_FLAGS):
+        return False
+    if isa == "avx2" and not cpu_has(("avx2", "fma")):
+        return False
+    return os.path.exists(_ref_path(isa=isa))
+
+
+def ref_lib(avx2=False, isa=None):
+    path = _ref_path(avx2, isa)
     if path not in _ref:
         if not os.path.exists(path):
             raise FileNotFoundError(path + " not built (make -C oracle ref needs /root/reference)")
@@ -204,8 +229,8 @@ def ref_lib(avx2=False):
 class RefSim:
     """One of the reference's own CPU implementations (--im cpu+naive|cpu+optim|cpu+simd|cpu+omp)."""
 
-    def __init__(self, tag, n, scheme="galaxy", soft=SOFT, dt=DT, avx2=False):
-        self.L = ref_lib(avx2)
+    def __init__(self, tag, n, scheme="galaxy", soft=SOFT, dt=DT, avx2=False, isa=None):
+        self.L = ref_lib(avx2, isa)
         self.h = self.L.murbref_create(tag.encode(), n, scheme.encode(), soft, dt)
         if not self.h:
             raise ValueError("unknown reference implementation tag " + tag)

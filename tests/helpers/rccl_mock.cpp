@@ -50,26 +50,23 @@ struct Comm {
     int device = 0;
     bool pinned = false;
 };
-struct PendingOp {
-    int kind;   // 0 all-gather, 1 reduce-scatter
-    const void* send; void* recv; size_t count; Comm* comm; hipStream_t stream;
-};
-// one process, several ranks: a ring of pinned staging buffers, each guarded by the events of its last use
+// one process, several ranks, each driven by ITS OWN THREAD (the library's ShardCrew): a ring of pinned staging
+// buffers, each guarded by the events of its last use; the threads meet at a barrier inside every call
 struct Staging {
     float* host = nullptr;
     size_t floats = 0;
-    std::vector<hipEvent_t> done;   // one per rank: recorded after that rank's host->device copy
-    bool used = false;
+    std::vector<hipEvent_t> copied;   // per rank: its contribution has reached the staging buffer
+    std::vector<hipEvent_t> done;     // per rank: recorded after that rank's host->device copy
+    std::atomic<bool> used{false};
 };
 struct LocalGroup {
-    int nranks = 0, alive = 0;
-    std::vector<PendingOp> pending;
+    int nranks = 0;
+    std::atomic<int> alive{0};
+    pthread_barrier_t barrier;        // among the ranks' threads
     Staging ring[4];
-    int next = 0;
-    std::vector<hipEvent_t> copied;   // per rank: its contribution has reached the staging buffer
+    std::vector<unsigned long> calls; // per rank: collectives issued so far (picks the staging buffer)
+    std::atomic<int> failed{0};
 };
-int group_depth = 0;
-std::vector<LocalGroup*> touched;   // groups with pending work inside the current ncclGroupStart/End
 struct Id { char bytes[128]; };
 std::string segment_name(const Id& id)
 {
@@ -130,6 +127,66 @@ void host_local_reduce(void* p)
         for (size_t k = 0; k < j->count; ++k) j->out[k] += src[k];
     }
     delete j;
+}
+
+// One collective of one rank of a one-process group, called by that rank's own thread; the threads of all ranks make the
+// same calls in the same order and meet inside.  Asynchronous like RCCL towards the GPU: copies and host functions on the
+// caller's stream, ordered by events — nothing is drained.  Staging layout: all-gather [rank][count]; reduce-scatter
+// [rank][nranks][count] followed by the results [rank][count].  (MURB_MOCK_MODE=sync: every step drained instead.)
+int run_local(Comm* c, int kind, const void* send, void* recv, size_t count, hipStream_t stream)
+{
+    LocalGroup* g = c->local;
+    const int r = c->rank;
+    const size_t n = (size_t)g->nranks;
+    const size_t per_rank = kind == 0 ? count : count * n;
+    const size_t need = per_rank * n + (kind == 1 ? count * n : 0);
+    Staging& st = g->ring[g->calls[(size_t)r]++ % 4];
+    const bool sync = !async_mode();
+    int rc = kOk;
+    if (st.used.load())   // its previous collective (four calls ago) must have left the buffer on every rank
+        for (hipEvent_t e : st.done)
+            if (hipEventSynchronize(e) != hipSuccess) rc = kSystem;
+    if (st.floats < need || st.copied.empty()) {   // same verdict on every thread: st changes only between two barriers
+        pthread_barrier_wait(&g->barrier);
+        if (r == 0) {
+            if (st.floats < need) {
+                if (st.host) (void)hipHostFree(st.host);
+                if (hipHostMalloc((void**)&st.host, need * 4, hipHostMallocDefault) != hipSuccess) { g->failed.store(1); st.host = nullptr; }
+                st.floats = st.host ? need : 0;
+            }
+            if (st.copied.empty()) {
+                st.copied.resize(n); st.done.resize(n);
+                for (size_t k = 0; k < n; ++k)
+                    if (hipEventCreateWithFlags(&st.copied[k], hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&st.done[k], hipEventDisableTiming) != hipSuccess) g->failed.store(1);
+            }
+        }
+        pthread_barrier_wait(&g->barrier);
+    }
+    if (g->failed.load()) rc = kSystem;
+    if (rc == kOk && (hipMemcpyAsync(st.host + (size_t)r * per_rank, send, per_rank * 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                      hipEventRecord(st.copied[(size_t)r], stream) != hipSuccess))
+        rc = kSystem;
+    if (rc == kOk && sync && hipStreamSynchronize(stream) != hipSuccess) rc = kSystem;
+    if (rc != kOk) g->failed.store(1);
+    pthread_barrier_wait(&g->barrier);   // every rank's `copied` event of this call is recorded
+    if (g->failed.load()) return kSystem;
+    for (size_t k = 0; k < n; ++k)
+        if (hipStreamWaitEvent(stream, st.copied[k], 0) != hipSuccess) return kSystem;
+    const float* src = st.host;
+    size_t floats = count * n;
+    if (kind == 1) {
+        float* out = st.host + per_rank * n + (size_t)r * count;
+        if (hipLaunchHostFunc(stream, host_local_reduce, new LocalReduceJob{st.host, out, count, (int)n, r}) != hipSuccess) return kSystem;
+        src = out;
+        floats = count;
+    }
+    if (hipMemcpyAsync(recv, src, floats * 4, hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipEventRecord(st.done[(size_t)r], stream) != hipSuccess)
+        return kSystem;
+    if (sync && hipStreamSynchronize(stream) != hipSuccess) return kSystem;
+    st.used.store(true);
+    return kOk;
 }
 }  // namespace
 
@@ -192,13 +249,15 @@ int ncclCommInitRank(void** out, int nranks, Id id, int rank)
     return kOk;
 }
 
-// one process, several "devices" (the same ordinal may repeat): the collectives are issued at ncclGroupEnd,
-// when every rank's call has been recorded
+// one process, several "devices" (the same ordinal may repeat); every communicator is then used by a thread of its own
 int ncclCommInitAll(void** out, int ndev, const int* devices)
 {
     if (!out || ndev < 1 || !devices) return kInvalid;
     LocalGroup* g = new LocalGroup;
-    g->nranks = g->alive = ndev;
+    g->nranks = ndev;
+    g->alive.store(ndev);
+    g->calls.assign((size_t)ndev, 0ul);
+    pthread_barrier_init(&g->barrier, nullptr, (unsigned)ndev);
     for (int r = 0; r < ndev; ++r) {
         Comm* c = new Comm;
         c->rank = r; c->nranks = ndev; c->local = g; c->device = devices[r];
@@ -217,8 +276,9 @@ int ncclCommDestroy(void* comm)
             for (Staging& s : c->local->ring) {
                 if (s.host) (void)hipHostFree(s.host);
                 for (hipEvent_t e : s.done) (void)hipEventDestroy(e);
+                for (hipEvent_t e : s.copied) (void)hipEventDestroy(e);
             }
-            for (hipEvent_t e : c->local->copied) (void)hipEventDestroy(e);
+            pthread_barrier_destroy(&c->local->barrier);
             delete c->local;
         }
         delete c;
@@ -239,12 +299,7 @@ int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* c
 {
     Comm* c = static_cast<Comm*>(comm);
     const size_t bytes = count * 4;
-    if (c && c->local) {
-        if (dtype != 7 || group_depth == 0) return kInvalid;
-        c->local->pending.push_back(PendingOp{0, send, recv, count, c, stream});
-        touched.push_back(c->local);
-        return kOk;
-    }
+    if (c && c->local) return dtype == 7 ? run_local(c, 0, send, recv, count, stream) : kInvalid;
     if (!c || dtype != 7 || bytes * c->nranks > kCapacity) return kInvalid;
     if (solo_mode()) return kOk;   // in place: the caller's slice is where it belongs, the others never arrive
     if (async_mode()) {
@@ -266,12 +321,7 @@ int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* c
 int ncclReduceScatter(const void* send, void* recv, size_t recvcount, int dtype, int op, void* comm, hipStream_t stream)
 {
     Comm* c = static_cast<Comm*>(comm);
-    if (c && c->local) {
-        if (dtype != 7 || op != 0 || group_depth == 0) return kInvalid;
-        c->local->pending.push_back(PendingOp{1, send, recv, recvcount, c, stream});
-        touched.push_back(c->local);
-        return kOk;
-    }
+    if (c && c->local) return (dtype == 7 && op == 0) ? run_local(c, 1, send, recv, recvcount, stream) : kInvalid;
     if (!c) return kInvalid;
     const size_t block = recvcount * 4, mine = block * c->nranks;
     if (dtype != 7 || op != 0 || mine * c->nranks + block * c->nranks > kCapacity) return kInvalid;
@@ -299,115 +349,8 @@ int ncclReduceScatter(const void* send, void* recv, size_t recvcount, int dtype,
     return kOk;
 }
 
-// one process, several ranks, synchronous form
-static int run_local_sync(LocalGroup* g)
-{
-    const int kind = g->pending[0].kind;
-    const size_t count = g->pending[0].count, n = (size_t)g->nranks;
-    std::vector<std::vector<float>> host(n);
-    for (const PendingOp& op : g->pending) {
-        const size_t floats = kind == 0 ? count : count * n;
-        host[op.comm->rank].resize(floats);
-        if (hipSetDevice(op.comm->device) != hipSuccess || hipStreamSynchronize(op.stream) != hipSuccess ||
-            hipMemcpy(host[op.comm->rank].data(), op.send, floats * 4, hipMemcpyDeviceToHost) != hipSuccess)
-            return kSystem;
-    }
-    for (const PendingOp& op : g->pending) {
-        std::vector<float> out(kind == 0 ? count * n : count, 0.f);
-        if (kind == 0)
-            for (size_t r = 0; r < n; ++r) std::copy(host[r].begin(), host[r].end(), out.begin() + r * count);
-        else
-            for (size_t r = 0; r < n; ++r)
-                for (size_t k = 0; k < count; ++k) out[k] += host[r][(size_t)op.comm->rank * count + k];
-        if (hipSetDevice(op.comm->device) != hipSuccess ||
-            hipMemcpy(op.recv, out.data(), out.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
-            return kSystem;
-    }
-    return kOk;
-}
-
-// ... asynchronous form: copies and host functions on the ranks' own streams, ordered by events.  Staging layout:
-// all-gather [rank][count]; reduce-scatter [rank][nranks][count] followed by the results [rank][count].
-static int run_local_async(LocalGroup* g)
-{
-    const int kind = g->pending[0].kind;
-    const size_t count = g->pending[0].count, n = (size_t)g->nranks;
-    const size_t per_rank = kind == 0 ? count : count * n;
-    const size_t need = per_rank * n + (kind == 1 ? count * n : 0);
-    Staging& st = g->ring[g->next];
-    g->next = (g->next + 1) % 4;
-    if (st.used)   // its previous collective (four calls ago) must have left the buffer
-        for (hipEvent_t e : st.done)
-            if (hipEventSynchronize(e) != hipSuccess) return kSystem;
-    if (st.floats < need) {
-        if (st.host) (void)hipHostFree(st.host);
-        if (hipHostMalloc((void**)&st.host, need * 4, hipHostMallocDefault) != hipSuccess) return kSystem;
-        st.floats = need;
-    }
-    if (st.done.empty()) {
-        st.done.resize(n);
-        for (hipEvent_t& e : st.done)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return kSystem;
-    }
-    if (g->copied.empty()) {
-        g->copied.resize(n);
-        for (hipEvent_t& e : g->copied)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return kSystem;
-    }
-    for (const PendingOp& op : g->pending) {
-        const int r = op.comm->rank;
-        if (hipSetDevice(op.comm->device) != hipSuccess ||
-            hipMemcpyAsync(st.host + (size_t)r * per_rank, op.send, per_rank * 4, hipMemcpyDeviceToHost, op.stream) != hipSuccess ||
-            hipEventRecord(g->copied[r], op.stream) != hipSuccess)
-            return kSystem;
-    }
-    for (const PendingOp& op : g->pending) {
-        const int r = op.comm->rank;
-        if (hipSetDevice(op.comm->device) != hipSuccess) return kSystem;
-        for (size_t k = 0; k < n; ++k)
-            if (hipStreamWaitEvent(op.stream, g->copied[k], 0) != hipSuccess) return kSystem;
-        const float* src = st.host;
-        size_t floats = count * n;
-        if (kind == 1) {
-            float* out = st.host + per_rank * n + (size_t)r * count;
-            if (hipLaunchHostFunc(op.stream, host_local_reduce, new LocalReduceJob{st.host, out, count, (int)n, r}) != hipSuccess)
-                return kSystem;
-            src = out;
-            floats = count;
-        }
-        if (hipMemcpyAsync(op.recv, src, floats * 4, hipMemcpyHostToDevice, op.stream) != hipSuccess ||
-            hipEventRecord(st.done[r], op.stream) != hipSuccess)
-            return kSystem;
-    }
-    st.used = true;
-    return kOk;
-}
-
-static int run_local(LocalGroup* g)
-{
-    if (g->pending.empty()) return kOk;
-    if ((int)g->pending.size() != g->nranks) return kInvalid;   // every rank must have made the same single call
-    for (const PendingOp& op : g->pending)
-        if (op.kind != g->pending[0].kind || op.count != g->pending[0].count) return kInvalid;
-    const int rc = async_mode() ? run_local_async(g) : run_local_sync(g);
-    g->pending.clear();
-    return rc;
-}
-
-int ncclGroupStart() { ++group_depth; return kOk; }
-int ncclGroupEnd()
-{
-    if (group_depth > 0 && --group_depth == 0) {
-        int rc = kOk;
-        std::vector<LocalGroup*> groups;
-        for (LocalGroup* g : touched)
-            if (std::find(groups.begin(), groups.end(), g) == groups.end()) groups.push_back(g);
-        touched.clear();
-        for (LocalGroup* g : groups) { const int r = run_local(g); if (r != kOk) rc = r; }
-        return rc;
-    }
-    return kOk;
-}
+int ncclGroupStart() { return kOk; }   // the library issues no grouped calls any more; kept for the binding
+int ncclGroupEnd() { return kOk; }
 const char* ncclGetErrorString(int code) { return code == kOk ? "no error" : code == kInvalid ? "mock: invalid argument" : "mock: system error"; }
 
 }  // extern "C"
