@@ -78,8 +78,15 @@ int murbhip_schedule_items(unsigned long n, int world, int rank, int split, int*
  * what murbhip_step builds for (n, world, rank) under the given plan (`split` i-side sub-blocks per block, `waves` 4 or 8
  * per workgroup, `taper_pct` % of each launch cut into finer items (+ 256: diagonal blocks as triangular pieces,
  * option "diag_tri"), `tri_first_pct` % of the own-slice triangle in its first launch; exchange_mode != 0 or world > 1: the three-launch pipeline with separate rows for the own-slice
- * triangle).  Per item 8 longs: first i slot, number of i bodies, j block, flags (bit 0 = diagonal), row set (0 main,
- * 1 own-slice triangle), float offset of its i-side output, of its j-side output, launch (0, 1, 2).  Per row-table
+ * triangle).  Per item 8 longs: first i slot, number of i bodies, j block, flags, row set (0 main,
+ * 1 own-slice triangle), float offset of its i-side output, of its j-side output, launch (0, 1, 2).
+ * flags, exactly as the kernel reads them (MurbSymItem::flags, csrc/murb_kernels_sym.h; SymPiece, csrc/murb_schedule.h):
+ *   bit 0      nothing is written on the j side (a diagonal item in its plain form - the full square with only the
+ *              i side kept - or the LAST triangular piece of a diagonal block, which has no later step to apply)
+ *   bit 1      diagonal item in its triangular form ("diag_tri"): the piece skips the j steps before its own
+ *   bits 8-11  triangular form: first j step (of 128 bodies) the piece evaluates
+ *   bits 12-15 triangular form: first j step whose terms are applied to BOTH sides (the steps before it, i.e. the
+ *              piece's own, keep the i side only)  Per row-table
  * entry 7 longs: row set, destination slice chunk, block inside it, offset and count of its i rows, offset and count of
  * its j rows (rows are 1024 slots).  NULL arrays query the counts.  Exists so that "every cell of every row has exactly
  * one writer" and "every pair is evaluated once" can be checked without a GPU. */
@@ -103,7 +110,10 @@ int murbhip_create(murbhip_ctx** out, unsigned long n, float soft, float g, int 
  * step).  `devices` lists HIP device ordinals; the same ordinal may appear more than once (the
  * shards then share that GPU — used to exercise the sharded path on a one-GPU machine).
  * exchange: 0 = device-to-device copies and peer reads issued by this library, 1 = RCCL (all-gather of
- * positions, reduce-scatter of accelerations under the pair-symmetric schedule; ncclCommInitAll). */
+ * positions, reduce-scatter of accelerations under the pair-symmetric schedule; ncclCommInitAll).
+ * Threading: the CALLER stays single-threaded (the reference's driver contract, main.cpp:348-354), but the context owns
+ * one host thread per shard that enqueues that shard's share of every step (murbhip_step returns when all of them have
+ * finished enqueueing, never waits for the GPU); each thread drives its own communicator, no ncclGroupStart/End. */
 int murbhip_create_sharded(murbhip_ctx** out, unsigned long n, float soft, float g, int ndev, const int* devices,
                            int exchange);
 
@@ -207,7 +217,10 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  *   "xcd_order"      variant 8: 0 (default) = j-major item order (round-robin dispatch then gives XCD x the i
  *                    blocks x mod 8 of every j block); 1 = one contiguous run of items per XCD (measured:
  *                    more L2 misses, same time; kept for the comparison)
- *   "profile"        1: bracket every force kernel with HIP events (read with murbhip_get_info)
+ *   "profile"        1: bracket every force kernel with HIP events (read with murbhip_get_info); 2: also both collectives
+ *                    on the exchange stream, the compute stream's waits for them (the EXPOSED part of the exchange) and
+ *                    the compute stream's whole step - ~16 more event records per step, meant for a short diagnostic
+ *                    run next to the timed one.  Setting it (to any value) drains the device and clears the samples
  *   "overlap"        sharded/rank mode: 0 = no overlap; 1 (default) = the own-slice work brackets the
  *                    exchanges on the compute stream; 2 = the own-slice triangle runs on a second,
  *                    lowest-priority compute stream next to the rectangle launch (pair-symmetric only)
@@ -225,7 +238,12 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  *                    CUs (8 = one per XCD, 16 = two per XCD) to the exchange stream.  The force kernels otherwise fill
  *                    every CU, and a collective's kernel (RCCL) has to wait ~0.1 ms for one of their workgroups to retire
  *                    (7 us with k = 8); but dispatch on a masked queue is slower: 6-8 % on long force launches, much more
- *                    on short ones.  bench.py times it per run for N > 1, like "tri_first_pct"
+ *                    on short ones.  bench.py times it per run for N > 1, like "tri_first_pct".
+ *                    Two side effects of hipExtStreamCreateWithCUMask, which has no flags argument: (i) a masked stream
+ *                    is BLOCKING with respect to the device's null stream, so a host application that works on stream 0
+ *                    of the same device (torch's default stream) synchronises with the force kernels implicitly;
+ *                    (ii) it has default priority.  The low-priority stream of "overlap" 2 therefore stays unmasked
+ *                    (it keeps its priority and may use the reserved CUs)
  *   "solo_shard"     r >= 0: in a sharded context only shard r launches force work (timing aid: the
  *                    isolated per-step timeline of one rank of W; results are meaningless).  -1 = off
  *   "force_exchange" 1: run the position exchange even with a single rank/shard (self-test of the
@@ -234,8 +252,15 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
 int murbhip_set_option(murbhip_ctx* ctx, const char* key, long value);
 
 /* Numeric facts.  Keys: "cu_count", "clock_mhz", "n", "slots", "world", "rank", "jsplit", "variant", "cu_reserve", "sym_passes", "sym_waves", "taper",
- * "workgroups", "force_launches", "force_ms_avg", "force_ms_total", "interactions_per_launch",
- * "device_bytes". */
+ * "workgroups", "interactions_per_launch", "device_bytes", and the timing spans of the steps since "profile" was set (HIP
+ * events on the library's own streams, all shards of this process; the call drains the device):
+ *   "force_launches", "force_ms_avg", "force_ms_total"      every force launch
+ *   "span_<kind>_ms_avg", "span_<kind>_count"               kind = tri1 | rect | tri2 (the three force launches of the exchange
+ *       pipeline), reduce_scatter | all_gather (exchange stream: from "my input is ready" to "my output has arrived"),
+ *       wait_gather | wait_reduce (compute stream idle, waiting for that collective), step (compute stream, first launch of
+ *       a step to the end of its state update); the last five need "profile" 2
+ *   "compute_wait_ms_per_step"                              (wait_gather + wait_reduce) per profiled step
+ *   "spans_dropped"                                         1 when the event pool (4096 spans per shard) ran out */
 int murbhip_get_info(murbhip_ctx* ctx, const char* key, double* value);
 
 #ifdef __cplusplus

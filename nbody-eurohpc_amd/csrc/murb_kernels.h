@@ -1,5 +1,5 @@
 // gfx950 (CDNA4) kernels of the all-pairs force + integrate path.  Device code only; included by
-// murbhip.hip (the C-ABI translation unit) and by tools/kernel_lab.hip (A/B timing of variants).
+// murbhip.hip (the C-ABI translation unit); variants are A/B-timed through the C ABI (tools/ab.py, tools/sweep.py).
 //
 // What is computed (reference SimulationNBodyOptim.cpp:34-94; device twin
 // SimulationNBodyCUDATileFullDevice.cu:110-137):

@@ -45,7 +45,9 @@ struct MurbSymItem {
     int i_slot0;          // first slot (global, multiple of WAVES * R) of the i range
     int ngroups;          // i groups of R bodies per WAVE
     int J;                // j block (staged in LDS)
-    int flags;            // bit 0: diagonal item (the i range lies inside block J): full square, i side kept only
+    int flags;            // bit 0: nothing is written on the j side (plain diagonal item: full square, i side kept only; or
+                          // the last triangular piece of a diagonal block); bit 1: diagonal item in its triangular form,
+                          // bits 8-11 its first j step, bits 12-15 its first j step applied both ways (SymPiece, murb_schedule.h)
     unsigned long ioff;   // float offset (component 0) where the i-side sums of slot i_slot0 go
     unsigned long joff;   // float offset (component 0) where the j-side sums of block J's first slot go
 };

@@ -209,7 +209,7 @@ int launch_force_t(const MurbForceArgs& a, int i_slots, hipStream_t s)
     return hip_rc(hipGetLastError());
 }
 
-// variant table: id -> (mode, R).  Keep in sync with DESIGN.md and tools/kernel_lab.hip.
+// variant table: id -> (mode, R).  Keep in sync with DESIGN.md 4.1 (tools/ab.py and tools/sweep.py select them by id).
 int launch_force(int variant, const MurbForceArgs& a, int i_slots, hipStream_t s)
 {
     switch (variant) {
@@ -786,21 +786,30 @@ void plan_sym_layout(int W, int r, int tb, int split, int waves, int taper, bool
 {
     std::vector<int> flat;
     int own = 0;
-    sym_schedule_items(W, r, tb, split, flat, &own, xcd_order);
-    // the launches of a step: one GPU = everything; exchange pipeline = triangle part 1, part 2, rectangles
-    const size_t n_all = flat.size() / 2;
-    const size_t t1 = (exchange_mode && overlap == 1) ? (size_t)((long)own * tri_first_pct / 100) : 0;
-    std::vector<size_t> launch_ends;
-    if (exchange_mode) {
-        if (t1 > 0) launch_ends.push_back(t1);
-        if ((size_t)own > t1) launch_ends.push_back((size_t)own);
-        if (n_all > (size_t)own) launch_ends.push_back(n_all);
-    } else {
-        launch_ends.push_back(n_all);
-    }
+    size_t t1 = 0;
     std::vector<SymPiece> pieces;
     std::vector<size_t> piece_ends;
-    sym_pieces(flat, split, taper, 16 * waves, diag_tri, launch_ends, pieces, piece_ends);
+    const auto build_pieces = [&](bool interleaved) {
+        sym_schedule_items(W, r, tb, split, flat, &own, interleaved);
+        // the launches of a step: one GPU = everything; exchange pipeline = triangle part 1, part 2, rectangles
+        const size_t n_all = flat.size() / 2;
+        t1 = (exchange_mode && overlap == 1) ? (size_t)((long)own * tri_first_pct / 100) : 0;
+        std::vector<size_t> launch_ends;
+        if (exchange_mode) {
+            if (t1 > 0) launch_ends.push_back(t1);
+            if ((size_t)own > t1) launch_ends.push_back((size_t)own);
+            if (n_all > (size_t)own) launch_ends.push_back(n_all);
+        } else {
+            launch_ends.push_back(n_all);
+        }
+        sym_pieces(flat, split, taper, 16 * waves, diag_tri, launch_ends, pieces, piece_ends);
+    };
+    build_pieces(xcd_order);
+    // Several passes share ONE row buffer and are cut at COLUMN boundaries (cut_passes takes a column to be a contiguous
+    // run of pieces with the same J): under the XCD-interleaved order a column is scattered over the table, a cut would
+    // fall inside it and an i row would keep an earlier pass's sums in the cells this pass does not write.  A problem
+    // that needs several passes is therefore always laid out in the plain j-major order.
+    if (!exchange_mode && xcd_order && cut_passes(pieces, budget_floats).size() > 1) build_pieces(false);
     size_t own_pieces = 0;   // pieces of the own-slice triangle = the leading ones whose j block is one of ours
     for (const SymPiece& pc : pieces) { if (pc.J / tb != r) break; ++own_pieces; }
     L.items.assign(pieces.size(), MurbSymItem{});
@@ -1175,20 +1184,21 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
 // not pre-empt resident workgroups: a collective's kernel would otherwise wait for a workgroup to retire before it can
 // start.  Bit b of the mask is CU b / 8 of XCD b % 8 (the driver deals the mask's bits to the XCDs round-robin), so
 // 8 reserved CUs are one per XCD, 16 two per XCD.  hipExtStreamCreateWithCUMask has no flags argument: such a stream
-// has the default (blocking with respect to stream 0) flag, harmless here since the library never uses stream 0.
+// has default priority and the default (blocking with respect to stream 0) flag — the library never uses stream 0, but a
+// host application that does (torch's default stream) then synchronises with the force kernels implicitly
+// (include/murbhip.h, "cu_reserve").  The low-priority stream of "overlap" 2 stays unmasked so that it keeps its priority.
 int create_compute_streams(const murbhip_ctx* c, Shard& sh, int reserve)
 {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    HIP_TRY(hipStreamCreateWithPriority(&sh.compute_low, hipStreamNonBlocking, least));
     if (reserve > 0 && c->cu_count > reserve) {
         std::vector<uint32_t> mask((size_t)(c->cu_count + 31) / 32, 0u);
         for (int b = 0; b < c->cu_count - reserve; ++b) mask[(size_t)b / 32] |= 1u << (b % 32);
         HIP_TRY(hipExtStreamCreateWithCUMask(&sh.compute, (uint32_t)mask.size(), mask.data()));
-        HIP_TRY(hipExtStreamCreateWithCUMask(&sh.compute_low, (uint32_t)mask.size(), mask.data()));
         return 0;
     }
     HIP_TRY(hipStreamCreateWithFlags(&sh.compute, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithPriority(&sh.compute_low, hipStreamNonBlocking, least));
     return 0;
 }
 
@@ -1291,7 +1301,7 @@ void pack_records(const murbhip_ctx* c, const float* x, const float* y, const fl
 // ===================================================================================== C ABI
 extern "C" {
 
-int murbhip_version(void) { return 101; }   // 1.01: murbhip_schedule_layout, the round-2 options
+int murbhip_version(void) { return 102; }   // 1.02: per-shard host threads, "profile" 2 and the span_* facts
 
 const char* murbhip_error_string(int code)
 {

@@ -1,6 +1,7 @@
 """Worker of tests/test_rank_mode_mock.py: ONE process driving several shards with exchange = RCCL
-(murbhip_create_sharded(..., exchange = 1): ncclCommInitAll + grouped collectives), all shards on GPU 0,
-collectives from the stand-in library (MURBHIP_RCCL_LIBRARY).  Prints "ok" when the sharded run matches the
+(murbhip_create_sharded(..., exchange = 1): ncclCommInitAll, then every shard's own host thread inside the library
+drives its communicator — no grouped calls), all shards on GPU 0, collectives from the stand-in library
+(MURBHIP_RCCL_LIBRARY), which makes the threads meet inside every call.  Prints "ok" when the sharded run matches the
 single-GPU run.    python _sharded_rccl_worker.py SHARDS N VARIANT OVERLAP"""
 import os
 import sys

@@ -68,6 +68,7 @@ def run_ranks(tmp_path, world, n, steps, variant, overlap=1, jsplit=0, integrato
     (4, 40000, 8, 1, 0, "async"),     # longer force launches: the collectives really do run beside them
     (2, 9000, 8, 1, 0, "sync"),       # the draining stand-in of round 1, for comparison
     (4, 20000, 8, 1, 4, "sync"),
+    (4, 30000, 0, 1, 0, "async"),     # BASELINE's N = 30 000 on 4 ranks with the plan the library picks itself (variant 0)
 ])
 def test_ranks_match_single_gpu(gpu, O, tmp_path, world, n, variant, overlap, jsplit, mode):
     steps = 3 if n < 40000 else 6
@@ -84,7 +85,7 @@ def test_ranks_match_single_gpu(gpu, O, tmp_path, world, n, variant, overlap, js
     vscale = max(np.abs(ref[k]).max() for k in ("vx", "vy", "vz"))
     covered = np.zeros(n, bool)
     for r, d in enumerate(ranks):
-        assert int(d["used_variant"]) == variant
+        assert int(d["used_variant"]) == (variant or int(ranks[0]["used_variant"])) and int(d["used_variant"]) in (1, 8)
         f, c = int(d["first"]), int(d["count"])
         covered[f:f + c] = True
         # every rank holds ALL gathered positions
@@ -155,7 +156,8 @@ def test_bench_py_with_several_ranks(gpu, world, n):
     if not os.path.exists(MOCK):
         subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "helpers")], check=True, timeout=600)
     env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK, MURB_BENCH_BACKEND="gloo", MURB_BENCH_SHARE_GPU="1",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+               MURB_BENCH_OTHER_CONFIGS="30000:10,60000:5")   # stand-ins for BASELINE's other sizes (the ranks share one GPU here)
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)               # bench.py must set it itself in this launch path
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--bodies",
            str(n), "--steps", "10", "--warmup", "2"]
@@ -171,6 +173,25 @@ def test_bench_py_with_several_ranks(gpu, world, n):
     assert "cpu_baseline" not in d      # rank 0 at N = 1 only
     assert d["tuned"]["tri_first_pct"] in (0, 25, 50, 75, 100) and len(d["tuned"]["ms_per_step_by_candidate"]) == 5
     assert d["tuned"]["cu_reserve"] in (0, 8, 16) and len(d["tuned"]["ms_per_step_by_cu_reserve"]) == 3
+    # a first real multi-GPU run must explain itself: both collectives and the compute stream's waits for them, event-timed
+    # on rank 0's streams; the one-sided (all-gather only) plan timed beside the half-ring one; the other sizes
+    ex = d["exchange"]
+    assert ex["steps_profiled"] == 10 and abs(ex["launches_per_step"] - 3) < 1e-9
+    for k in ("reduce_scatter_ms_avg", "all_gather_ms_avg", "compute_stream_step_ms_avg", "ms_per_step_with_profiling"):
+        assert ex[k] > 0, (k, ex)
+    for k in ("compute_wait_gather_ms_avg", "compute_wait_reduce_ms_avg"):
+        assert 0 <= ex[k] <= ex["compute_stream_step_ms_avg"], (k, ex)
+    assert abs(ex["compute_wait_ms_avg"] - ex["compute_wait_gather_ms_avg"] - ex["compute_wait_reduce_ms_avg"]) < 1e-6
+    assert all(v > 0 for v in ex["force_ms_avg"].values())
+    assert ex["payload_bytes_per_rank"]["all_gather_out"] == world * ex["payload_bytes_per_rank"]["all_gather_in"]
+    alt = d["one_sided_plan"]
+    assert alt["ms_per_step"] > 0 and abs(alt["half_ring_speedup"] - alt["ms_per_step"] / d["ms_per_step"]) < 1e-9
+    oc = {e["n_bodies"]: e for e in d["other_configs"]}
+    assert set(oc) == {30000, 60000}
+    for e in oc.values():
+        assert e["value"] > 0 and e["roofline"]["kernel_ms_avg"] > 0 and abs(e["value"] - float(e["n_bodies"]) ** 2 * e["steps"] / (e["ms_per_step"] * e["steps"] * 1e-3)) / e["value"] < 1e-6
+    assert oc[60000]["plan"]["kernel_variant"] == 8 or world == 4     # a rank of 4 at 60 000 bodies falls back to the one-sided plan
+    assert "environment" not in d
 
 
 def test_bench_py_launches_its_own_ranks(gpu):
@@ -184,7 +205,7 @@ def test_bench_py_launches_its_own_ranks(gpu):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bodies", "40000", "--steps", "6",
-                        "--warmup", "1", "--cu-reserve", "8"], capture_output=True, text=True, timeout=600, env=env)
+                        "--warmup", "1", "--cu-reserve", "8", "--no-other-configs"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -210,13 +231,33 @@ def test_bench_py_watchdog_reports_a_stuck_phase(gpu):
     d = json.loads(lines[0])
     assert d["value"] is None and "no progress in phase" in d["error"] and d["phase"]
     assert "giving up" in r.stderr
+    # the line names the settings a failed multi-GPU start depends on
+    assert d["environment"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and d["environment"]["MURBHIP_RCCL_LIBRARY"] == MOCK
+
+
+def test_bench_py_reports_a_failed_start(gpu):
+    """N > 1 with a collective library that cannot be loaded: the run must end at once with ONE JSON line from rank 0 whose
+    "error" carries the library's message and the phase, and a non-zero exit code."""
+    import json
+    env = dict(os.environ, MURBHIP_RCCL_LIBRARY="none", MURB_BENCH_BACKEND="gloo", MURB_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bodies", "40000", "--steps", "5",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, (r.stdout, r.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["value"] is None and "librccl could not be loaded" in d["error"] and d["phase"] == "context + upload"
 
 
 @pytest.mark.parametrize("shards,n,variant,overlap", [(2, 9000, 8, 1), (3, 9001, 8, 0), (4, 20000, 8, 1), (3, 9000, 1, 1)])
 def test_one_process_several_shards_over_rccl_calls(gpu, shards, n, variant, overlap):
-    """`--im hip+tile+multi` on a multi-GPU node = murbhip_create_sharded(..., exchange = RCCL): ncclCommInitAll and
-    one ncclGroupStart/End around the shards' all-gather (and reduce-scatter) calls.  With all shards on GPU 0 the
-    calls go to the stand-in library, which executes them at ncclGroupEnd."""
+    """`--im hip+tile+multi` on a multi-GPU node = murbhip_create_sharded(..., exchange = RCCL): ncclCommInitAll, then
+    every shard's own host thread (the library's ShardCrew) issues that shard's all-gather and reduce-scatter on its own
+    communicator — no ncclGroupStart/End.  With all shards on GPU 0 the calls go to the stand-in library, whose local mode
+    makes the callers' threads meet inside every collective and moves the data with copies and host functions on the
+    callers' streams (asynchronous towards the GPU, like RCCL)."""
     if not os.path.exists(MOCK):
         subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "helpers")], check=True, timeout=600)
     env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK)

@@ -4,7 +4,7 @@
 set -o pipefail
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$1"; shift
-ARGS=("$@"); [ ${#ARGS[@]} -eq 0 ] && ARGS=(--steps 10 --warmup 2 --no-cpu-baseline)
+ARGS=("$@"); [ ${#ARGS[@]} -eq 0 ] && ARGS=(--steps 10 --warmup 2 --no-cpu-baseline --no-other-configs)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for grp in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES" "grbm:GRBM_GUI_ACTIVE" "lds:SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS"; do

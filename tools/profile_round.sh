@@ -10,11 +10,11 @@ cd /tmp && export TMPDIR=/tmp
 for cfg in "30k:30000:100" "200k:200000:50" "1m:1000000:10"; do
     name="${cfg%%:*}"; rest="${cfg#*:}"; n="${rest%%:*}"; steps="${rest#*:}"
     rm -rf "$OUT/trace_$name"
-    rocprofv3 --kernel-trace --stats -d "$OUT/trace_$name" -o run --output-format csv -- python3 "$R/bench.py" --bodies "$n" --steps "$steps" --warmup 5 --no-cpu-baseline \
+    rocprofv3 --kernel-trace --stats -d "$OUT/trace_$name" -o run --output-format csv -- python3 "$R/bench.py" --bodies "$n" --steps "$steps" --warmup 5 --no-cpu-baseline --no-other-configs \
         > "$OUT/${TAG}_bench_n${name}_under_rocprof.json" 2> "$OUT/trace_$name.err" || { echo "trace $name failed"; tail -5 "$OUT/trace_$name.err"; exit 1; }
     cp "$(find "$OUT/trace_$name" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_n${name}_kernel_stats.csv"
     echo "trace $name done"
-    bash "$R/tools/pmc_passes.sh" "$OUT/pmc_$name" --bodies "$n" --steps 10 --warmup 2 --no-cpu-baseline || exit 1
+    bash "$R/tools/pmc_passes.sh" "$OUT/pmc_$name" --bodies "$n" --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs || exit 1
     python3 "$R/tools/pmc_summary.py" "$OUT/pmc_$name" "$OUT/${TAG}_bench_n${name}_pmc_summary.csv" "$OUT/traffic_$name.json" "$n"
     echo "pmc $name done"
 done
