@@ -62,25 +62,98 @@ void xcd_interleave(std::vector<int>& flat, size_t first_item, size_t end_item)
         }
 }
 
-void sym_schedule_items(int world, int rank, int tb, int split, std::vector<int>& flat, int* own, bool xcd_order = false)
+// How many REAL bodies each block holds: slice s keeps its counts[s] bodies in its first slots, the rest of its tb blocks
+// is zero-mass padding (at most the last block of a slice is partly filled; a whole block is empty only when a slice
+// holds one body fewer than the largest and that body was alone in its block — such a block counts as holding one body,
+// so that every block keeps its items and its entry in the row tables, which the fused row sum + update indexes by block).
+struct SymFill {
+    int tb = 0;
+    std::vector<int> count;   // bodies per slice
+    int of(int block) const
+    {
+        const int left = count[(size_t)(block / tb)] - (block % tb) * MURB_SLICE_ALIGN;
+        return left <= 1 ? 1 : (left >= MURB_SLICE_ALIGN ? MURB_SLICE_ALIGN : left);
+    }
+};
+inline SymFill sym_fill(unsigned long n, int world)
 {
-    const int W = world, r = rank, ts = tb * split;
+    SymFill f;
+    f.tb = (int)(slice_slots(n, world) / MURB_SLICE_ALIGN);
+    for (int s = 0; s < world; ++s) {
+        unsigned long first, count;
+        partition(n, world, s, &first, &count);
+        f.count.push_back((int)count);
+    }
+    return f;
+}
+
+// Which side of a block pair is walked (i side) and which is staged in LDS (j side).  The kernel's cost is (i bodies
+// walked) x 1024: the j block is always staged whole, the i range can be any multiple of 16 x waves bodies.  So the block
+// with FEWER real bodies goes on the i side and only its real part is walked — padding bodies have zero mass and
+// contribute exactly 0 to every sum, and nobody reads theirs.  (N = 30 000: the last of 30 blocks holds 304 bodies and
+// takes part in 30 of the 465 block pairs; a rank of 8 at N = 200 000: 424 of 1024 in the last block of every slice,
+// 7.6 % of a rank's block pairs.)  `def_i`, `def_j`: the orientation the schedule would otherwise use.
+inline void sym_orient(const SymFill& fill, int def_i, int def_j, int* i_block, int* j_block)
+{
+    const bool swap = def_i != def_j && fill.of(def_j) < fill.of(def_i);
+    *i_block = swap ? def_j : def_i;
+    *j_block = swap ? def_i : def_j;
+}
+// the sub-blocks of block `i_block` that hold real bodies, against block `j_block`
+inline void sym_push_block_pair(const SymFill& fill, int split, int i_block, int j_block, std::vector<int>& flat)
+{
+    const int len = MURB_SLICE_ALIGN / split, real = fill.of(i_block);
+    for (int q = 0; q < split && q * len < real; ++q) { flat.push_back(i_block * split + q); flat.push_back(j_block); }
+}
+
+void sym_schedule_items(int world, int rank, int tb, int split, const SymFill& fill, std::vector<int>& flat, int* own, bool xcd_order = false)
+{
+    const int W = world, r = rank;
     flat.clear();
     for (int j = 0; j < tb; ++j)
-        for (int i = 0; i < (j + 1) * split; ++i) { flat.push_back(r * ts + i); flat.push_back(r * tb + j); }
+        for (int a = 0; a <= j; ++a) {
+            int ib, jb;
+            sym_orient(fill, r * tb + a, r * tb + j, &ib, &jb);
+            sym_push_block_pair(fill, split, ib, jb, flat);
+        }
     *own = (int)flat.size() / 2;
     for (int d = 1; d <= W / 2; ++d) {
         const int s = (r + d) % W;
         if (s == r) continue;
         const bool shared = (W % 2 == 0) && d == W / 2;
-        const int lo = std::min(r, s), hb = (tb + 1) / 2;
-        for (int i = 0; i < ts; ++i)
-            for (int j = 0; j < tb; ++j) {
-                // i: OWN sub-blocks (walked, i side); j: the other slice's blocks (LDS resident, j side)
-                if (shared && !((r == lo) ? (i / split < hb) : (j >= hb))) continue;
-                flat.push_back(r * ts + i);
-                flat.push_back(s * tb + j);
+        const int lo = std::min(r, s);
+        // the shared slice pair is cut at a block boundary of the LOWER rank's slice so that both halves hold the same
+        // number of real bodies as nearly as possible (the last block of a slice is partly empty and cheap to walk);
+        // both ranks compute the same cut
+        int hb = (tb + 1) / 2;
+        if (shared) {
+            long total = 0, acc = 0, best = -1;
+            for (int a = 0; a < tb; ++a) total += fill.of(lo * tb + a);
+            for (int h = 0; h <= tb; ++h) {
+                const long off = 2 * acc > total ? 2 * acc - total : total - 2 * acc;
+                if (best < 0 || off <= best) { best = off; hb = h; }
+                if (h < tb) acc += fill.of(lo * tb + h);
             }
+        }
+        std::vector<int> swapped;
+        for (int a = 0; a < tb; ++a) {
+            const size_t row_first = flat.size();
+            for (int j = 0; j < tb; ++j) {
+                // a: OWN block (by default walked, i side); j: the other slice's block (LDS resident, j side)
+                if (shared && !((r == lo) ? (a < hb) : (j >= hb))) continue;
+                int ib, jb;
+                sym_orient(fill, r * tb + a, s * tb + j, &ib, &jb);
+                if (ib == r * tb + a) { flat.push_back(ib); flat.push_back(jb); }   // expanded into sub-blocks below
+                else sym_push_block_pair(fill, split, ib, jb, swapped);             // the other slice's emptier block is walked
+            }
+            // i-major order as before: sub-block q of block a against every j of the row, then q + 1
+            const std::vector<int> row(flat.begin() + (long)row_first, flat.end());
+            flat.resize(row_first);
+            const int len = MURB_SLICE_ALIGN / split, real = fill.of(r * tb + a);
+            for (int q = 0; q < split && q * len < real; ++q)
+                for (size_t k = 0; k < row.size(); k += 2) { flat.push_back(row[k] * split + q); flat.push_back(row[k + 1]); }
+        }
+        flat.insert(flat.end(), swapped.begin(), swapped.end());
     }
     // the three launches of a step: first half of the own-slice triangle, second half, rectangles
     if (!xcd_order) return;
@@ -113,7 +186,9 @@ constexpr int kSymStepBodies = 128;
 //   diag_tri: a diagonal block (i block == j block) is cut into pieces of at most 128 bodies, each evaluating only the
 //     j steps from its own on: its own step one-sided, the later ones both ways — 36 instead of 64 step units per
 //     diagonal block (plain form: the full square, i side kept).
-inline void sym_pieces(const std::vector<int>& flat, int split, int taper_pct, int min_len, bool diag_tri,
+//   fill: a piece that lies entirely in a block's padding is dropped, one that straddles the end of the real bodies is cut
+//     to the next multiple of `min_len` (sym_orient put the emptier block of a pair on this, the i side).
+inline void sym_pieces(const std::vector<int>& flat, int split, int taper_pct, int min_len, bool diag_tri, const SymFill& fill,
                        const std::vector<size_t>& launch_ends, std::vector<SymPiece>& out, std::vector<size_t>& piece_launch_ends)
 {
     const int len = MURB_SLICE_ALIGN / split;
@@ -133,8 +208,11 @@ inline void sym_pieces(const std::vector<int>& flat, int split, int taper_pct, i
             }
             if (diag && diag_tri)
                 while (len / div > kSymStepBodies && len / (2 * div) >= min_len) div *= 2;
+            const int real_end = (isub / split) * MURB_SLICE_ALIGN + fill.of(isub / split);   // first padding slot of the i block
             for (int q = 0; q < div; ++q) {
                 SymPiece pc{isub * len + q * (len / div), len / div, J, diag ? 1 : 0};
+                if (pc.i_slot0 >= real_end) break;
+                if (pc.i_slot0 + pc.len > real_end) pc.len = (real_end - pc.i_slot0 + min_len - 1) / min_len * min_len;
                 if (diag && diag_tri && pc.len <= kSymStepBodies) {
                     const int in_block = pc.i_slot0 % MURB_SLICE_ALIGN;
                     const int a = in_block / kSymStepBodies, b = (in_block + pc.len + kSymStepBodies - 1) / kSymStepBodies;

@@ -781,16 +781,17 @@ struct SymHostLayout {
     std::vector<SymPass> passes;              // of the main set
 };
 
-void plan_sym_layout(int W, int r, int tb, int split, int waves, int taper, bool diag_tri, bool exchange_mode, int overlap,
+void plan_sym_layout(int W, int r, const SymFill& fill, int split, int waves, int taper, bool diag_tri, bool exchange_mode, int overlap,
                      int tri_first_pct, bool xcd_order, size_t budget_floats, SymHostLayout& L)
 {
+    const int tb = fill.tb;
     std::vector<int> flat;
     int own = 0;
     size_t t1 = 0;
     std::vector<SymPiece> pieces;
     std::vector<size_t> piece_ends;
     const auto build_pieces = [&](bool interleaved) {
-        sym_schedule_items(W, r, tb, split, flat, &own, interleaved);
+        sym_schedule_items(W, r, tb, split, fill, flat, &own, interleaved);
         // the launches of a step: one GPU = everything; exchange pipeline = triangle part 1, part 2, rectangles
         const size_t n_all = flat.size() / 2;
         t1 = (exchange_mode && overlap == 1) ? (size_t)((long)own * tri_first_pct / 100) : 0;
@@ -802,7 +803,7 @@ void plan_sym_layout(int W, int r, int tb, int split, int waves, int taper, bool
         } else {
             launch_ends.push_back(n_all);
         }
-        sym_pieces(flat, split, taper, 16 * waves, diag_tri, launch_ends, pieces, piece_ends);
+        sym_pieces(flat, split, taper, 16 * waves, diag_tri, fill, launch_ends, pieces, piece_ends);
     };
     build_pieces(xcd_order);
     // Several passes share ONE row buffer and are cut at COLUMN boundaries (cut_passes takes a column to be a contiguous
@@ -810,8 +811,11 @@ void plan_sym_layout(int W, int r, int tb, int split, int waves, int taper, bool
     // fall inside it and an i row would keep an earlier pass's sums in the cells this pass does not write.  A problem
     // that needs several passes is therefore always laid out in the plain j-major order.
     if (!exchange_mode && xcd_order && cut_passes(pieces, budget_floats).size() > 1) build_pieces(false);
-    size_t own_pieces = 0;   // pieces of the own-slice triangle = the leading ones whose j block is one of ours
-    for (const SymPiece& pc : pieces) { if (pc.J / tb != r) break; ++own_pieces; }
+    // pieces of the own-slice triangle = those of the launches before the rectangles' (a rectangle item may have an own
+    // block on its j side: sym_orient puts the emptier block of a pair on the i side)
+    size_t own_pieces = pieces.size();
+    if (exchange_mode && flat.size() / 2 > (size_t)own) own_pieces = piece_ends.size() >= 2 ? piece_ends[piece_ends.size() - 2] : 0;
+    (void)tb;
     L.items.assign(pieces.size(), MurbSymItem{});
     L.table_main.clear(); L.table_tri.clear();
     L.floats_main = L.floats_tri = 0;
@@ -864,7 +868,7 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
     sh.sym_bytes = 0;
 
     SymHostLayout L;
-    plan_sym_layout(c->world, sh.rank, (int)(c->slice / MURB_SYM_BLOCK), p.split, p.waves, p.taper, p.diag_tri, exchange_mode,
+    plan_sym_layout(c->world, sh.rank, sym_fill(c->n, c->world), p.split, p.waves, p.taper, p.diag_tri, exchange_mode,
                     c->overlap, c->tri_first_pct, c->xcd_order != 0, sym_pass_budget(c) / (3 * sizeof(float)), L);
     if (!exchange_mode && L.passes.size() == 1 && (int)L.table_main.size() != (int)(c->slots / MURB_SYM_BLOCK))
         return MURBHIP_E_STATE;   // the fused row sum + integrate walks every block
@@ -1353,7 +1357,7 @@ int murbhip_schedule_items(unsigned long n, int world, int rank, int split, int*
     if (split != 1 && split != 2 && split != 4 && split != 8 && split != 16) return MURBHIP_E_INVALID;
     std::vector<int> flat;
     int own = 0;
-    sym_schedule_items(world, rank, (int)(slice_slots(n, world) / MURB_SYM_BLOCK), split, flat, &own);
+    sym_schedule_items(world, rank, (int)(slice_slots(n, world) / MURB_SYM_BLOCK), split, sym_fill(n, world), flat, &own);
     *count = flat.size() / 2;
     *own_count = (unsigned long)own;
     if (pairs) {
@@ -1374,7 +1378,7 @@ int murbhip_schedule_layout(unsigned long n, int world, int rank, int split, int
         return MURBHIP_E_INVALID;
     if (MURB_SYM_BLOCK / split < 16 * waves) return MURBHIP_E_INVALID;
     SymHostLayout L;
-    plan_sym_layout(world, rank, (int)(slice_slots(n, world) / MURB_SYM_BLOCK), split, waves, taper_pct & 0xff, (taper_pct & 0x100) != 0,
+    plan_sym_layout(world, rank, sym_fill(n, world), split, waves, taper_pct & 0xff, (taper_pct & 0x100) != 0,
                     exchange_mode != 0 || world > 1, 1, tri_first_pct, false, 0, L);
     *item_count = L.items.size();
     *row_count = L.table_main.size() + L.table_tri.size();

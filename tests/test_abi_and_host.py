@@ -130,45 +130,63 @@ def test_driver_cli_contract():
     assert r.returncode == 255 and "Softening factor can't be equal to 0" in r.stdout
 
 
+def real_bodies_per_block(mh, n, world):
+    """Real (non-padding) bodies of every global block: slice s keeps its bodies in its first slots."""
+    tb = mh.slice_slots(n, world) // 1024
+    fill = np.zeros(world * tb, np.int64)
+    for sl in range(world):
+        cnt = mh.partition(n, world, sl)[1]
+        for b in range(tb):
+            fill[sl * tb + b] = min(1024, max(0, cnt - b * 1024))
+    return fill
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 4, 5, 6, 8])
-@pytest.mark.parametrize("n,split", [(9000, 1), (9000, 4), (30000, 2), (200000, 1)])
+@pytest.mark.parametrize("n,split", [(9000, 1), (9000, 4), (30000, 2), (200000, 1), (2049, 2)])
 def test_half_ring_schedule_covers_every_pair_once(mh, n, world, split):
-    """Multi-GPU pair-symmetric schedule (murbhip_schedule_items, host only): over all ranks every
-    unordered pair of (sub-block, block) cells is listed exactly once, each rank's share is balanced,
-    and a rank only ever walks sub-blocks of its own slice on the i side."""
+    """Multi-GPU pair-symmetric schedule (murbhip_schedule_items, host only): over all ranks every unordered pair of
+    (sub-block, sub-block) cells that hold REAL bodies is covered exactly once (padding never twice), each rank's share is
+    balanced, a rank's triangle stays inside its own slice and every rectangle item has an own block on one side.  The
+    emptier block of a pair is the walked (i) side and its padding sub-blocks are not walked at all."""
     if n // world < 1024 and world > 4:
         pytest.skip("slices of one block: nothing to balance")
     tb = mh.slice_slots(n, world) // 1024
     ts = tb * split
+    sub = 1024 // split
+    fill = real_bodies_per_block(mh, n, world)
+    real_sub = np.array([fill[u // split] > (u % split) * sub for u in range(world * ts)])   # sub-block holds a real body
     seen = {}
     counts = []
     for r in range(world):
         items, own = mh.schedule_items(n, world, r, split)
-        counts.append(len(items))
-        assert own == split * tb * (tb + 1) // 2
+        # a rank's work: bodies it walks (each against a staged block of 1024)
+        counts.append(sum(min(sub, max(1, int(fill[i // split])) - (i % split) * sub) for i, _ in items.tolist()))
+        assert own <= split * tb * (tb + 1) // 2
+        mine = lambda blk: r * tb <= blk < (r + 1) * tb   # noqa: E731
         for k, (i, j) in enumerate(items.tolist()):
-            assert r * ts <= i < (r + 1) * ts, "i side must be an own sub-block"
+            bi = i // split
             if k < own:
-                assert r * tb <= j < (r + 1) * tb and i // split <= j
+                assert mine(bi) and mine(j), "the own-slice triangle needs no remote data"
             else:
-                assert not (r * tb <= j < (r + 1) * tb)
-            # canonical key of the unordered cell {sub-block i, block j}: own-slice items are ordered
-            # (block(i) <= j) and unique by construction; a rectangle cell {i, j} could also be listed by
-            # the rank owning j as (some sub-block of j, block(i)): express both in sub-block pairs
+                assert mine(bi) != mine(j), "a rectangle item pairs an own block with another slice's"
+            assert fill[bi] <= fill[j] or bi == j, "the emptier block of a pair is the walked one"
+            assert real_sub[i] or (i % split == 0), "a padding sub-block is never walked (a block's first one always is)"
+            # canonical key of the unordered cell {sub-block i, sub-block jj}; diagonal blocks evaluate both orders
+            # inside the item
             for jj in range(j * split, (j + 1) * split):
-                if i // split == j:            # diagonal block: both orders evaluated inside the item
-                    key = ("diag", i, jj)
-                else:
-                    key = ("off", min(i, jj), max(i, jj))
+                key = ("diag", i, jj) if bi == j else ("off", min(i, jj), max(i, jj))
                 seen[key] = seen.get(key, 0) + 1
     assert all(v == 1 for v in seen.values()), "a cell is evaluated twice"
-    total_sub = world * ts
-    off = sum(1 for k in seen if k[0] == "off")
-    diag = sum(1 for k in seen if k[0] == "diag")
-    assert diag == world * tb * split * split                      # every (sub-block, sub-block) cell of a diagonal block
-    assert off == (total_sub * total_sub - world * tb * split * split) // 2   # every other unordered pair exactly once
+    # every cell with real bodies on both sides is there
+    real_ids = np.flatnonzero(real_sub)
+    for u in real_ids:
+        for v in real_ids:
+            if u // split == v // split:
+                assert ("diag", int(u), int(v)) in seen
+            elif u < v:
+                assert ("off", int(u), int(v)) in seen
     if world > 1 and tb >= 2:
-        assert max(counts) - min(counts) <= split * tb, counts     # balanced up to one block row
+        assert max(counts) - min(counts) <= 1024 * tb, counts      # balanced up to one block row (walked bodies)
 
 
 @pytest.mark.parametrize("diag_tri", [False, True])
@@ -176,19 +194,26 @@ def test_half_ring_schedule_covers_every_pair_once(mh, n, world, split):
     (5000, 1, 1, 4, 0, False), (5000, 1, 4, 4, 0, False), (9000, 1, 8, 8, 0, False), (9000, 1, 2, 4, 50, False),
     (9000, 1, 8, 8, 40, False), (9000, 1, 16, 4, 100, False), (3000, 1, 1, 4, 0, True),      # one rank with the exchange pipeline (RCCL self-test)
     (9000, 2, 1, 4, 0, True), (9001, 3, 2, 4, 30, True), (20000, 4, 4, 4, 0, True), (20000, 4, 2, 8, 60, True),
-    (30000, 5, 1, 4, 0, True), (60000, 8, 4, 4, 25, True),
+    (30000, 5, 1, 4, 0, True), (60000, 8, 4, 4, 25, True), (30000, 1, 4, 8, 30, False), (2049, 2, 2, 4, 0, True),
 ])
 def test_pair_symmetric_layout_is_complete_and_collision_free(mh, n, world, split, waves, taper, exchange, diag_tri):
     """What the pair-symmetric kernel is handed (murbhip_schedule_layout, host only), for every rank of a run:
-      * every ordered (i, j) interaction is applied exactly once over all items of all ranks (at the granularity of
-        16 slots), with any item size mix the taper produces;
-      * every cell of every partial row has exactly one writer;
-      * pushing "how many bodies did this cell's writer sum over" through the row tables, the reduce-scatter chunk
-        layout and the own-triangle addend gives every slot exactly `slots` interactions — i.e. the data flow of a
-        step, launch by launch, loses and duplicates nothing."""
+      * every ordered (i, j) interaction between REAL bodies is applied exactly once over all items of all ranks (at the
+        granularity of 16 slots), with any item size mix the taper produces; nothing is applied twice;
+      * every cell of every partial row has at most one writer, and exactly one where the slot holds a real body;
+      * pushing "how many REAL bodies did this cell's writer sum over" through the row tables, the reduce-scatter chunk
+        layout and the own-triangle addend gives every real slot exactly n interactions — i.e. the data flow of a step,
+        launch by launch, loses and duplicates nothing;
+      * padding is walked only up to the next multiple of 16 x waves bodies behind a block's last real body."""
     slice_ = mh.slice_slots(n, world)
     slots, tb = slice_ * world, slice_ // 1024
     G = 16
+    fill = real_bodies_per_block(mh, n, world)
+    real = np.zeros(slots, bool)
+    for b, f in enumerate(fill):
+        real[b * 1024:b * 1024 + f] = True
+    assert real.sum() == n
+    nreal = lambda lo, hi: int(real[lo:hi].sum())   # noqa: E731
     count = np.zeros((slots // G, slots // G), np.int32)
     recv = np.zeros((world, slice_), np.int64)     # what the reduce-scatter delivers: sum over ranks of their chunk for a slice
     own = np.zeros((world, slice_), np.int64)      # own-triangle row sums (exchange pipeline) / everything (one GPU)
@@ -196,38 +221,54 @@ def test_pair_symmetric_layout_is_complete_and_collision_free(mh, n, world, spli
         items, rows, fm, ft = mh.schedule_layout(n, world, r, split, waves, taper, 50, exchange, diag_tri)
         assert len(items) > 0
         sets = {0: np.zeros(fm, np.int32), 1: np.zeros(ft, np.int32)}      # writers per cell
-        vals = {0: np.zeros(fm, np.int64), 1: np.zeros(ft, np.int64)}      # bodies summed into the cell
+        vals = {0: np.zeros(fm, np.int64), 1: np.zeros(ft, np.int64)}      # real bodies summed into the cell
+        needs = {0: np.zeros(fm, bool), 1: np.zeros(ft, bool)}             # cells that belong to a real slot
         launches = items[:, 7]
         assert (np.diff(launches) >= 0).all()                              # launch order
         for i0, ln, J, flags, st, ioff, joff, launch in items:
             assert ln % (4 * waves) == 0 and ln >= 16 * waves and i0 % (4 * waves) == 0 and i0 // 1024 == (i0 + ln - 1) // 1024
-            diag = i0 // 1024 == J
+            bi = i0 // 1024
+            assert i0 % 1024 < max(fill[bi], 1), "an item that walks nothing but padding"
+            assert i0 % 1024 + ln < max(fill[bi], 1) + 16 * waves, "padding is walked only up to the item granule"
+            diag = bi == J
             j_side, tri = not (flags & 1), bool(flags & 2)
             assert diag or (j_side and not tri)
-            assert tri == (diag and diag_tri)
+            assert tri == (diag and diag_tri and ln <= 128)
             if exchange or world > 1:
                 assert st == (1 if launch < 2 else 0)
-                assert (i0 // 1024) // tb == r                              # a rank walks its own bodies on the i side
+                if st == 1:
+                    assert bi // tb == r and J // tb == r                    # the triangle needs no remote data
+                else:
+                    assert (bi // tb == r) != (J // tb == r)                 # a rectangle: one own block, one of another slice
+            assert fill[bi] <= fill[J]                                       # the emptier block is the walked one
             # which j steps (of 128 bodies) the item evaluates, and from which one on it applies both sides
             p_first, p_sym = ((flags >> 8) & 15, (flags >> 12) & 15) if tri else (0, 8 if diag else 0)
             if tri:
                 assert ln <= 128 and p_first == (i0 % 1024) // 128 and p_sym == p_first + 1
-            assert j_side == (p_sym < 8)
+            assert j_side == (p_sym < 8) or (tri and not j_side)             # the last REAL triangular piece may have later (padding) steps
             j0 = J * 1024
             count[i0 // G:(i0 + ln) // G, (j0 + 128 * p_first) // G:(j0 + 1024) // G] += 1
             sets[st][ioff:ioff + ln] += 1
-            vals[st][ioff:ioff + ln] += 128 * (8 - p_first)
+            needs[st][ioff:ioff + ln] |= real[i0:i0 + ln]
+            vals[st][ioff:ioff + ln] += nreal(j0 + 128 * p_first, j0 + 1024)
             if j_side:
                 count[(j0 + 128 * p_sym) // G:(j0 + 1024) // G, i0 // G:(i0 + ln) // G] += 1
                 sets[st][joff:joff + 1024] += 1
-                vals[st][joff + 128 * p_sym:joff + 1024] += ln
+                needs[st][joff:joff + 1024] |= real[j0:j0 + 1024]
+                vals[st][joff + 128 * p_sym:joff + 1024] += nreal(i0, i0 + ln)
         for st in (0, 1):
-            assert (sets[st] == 1).all(), (r, st, np.unique(sets[st]))
+            assert (sets[st] <= 1).all(), (r, st, np.unique(sets[st]))       # never two writers
         seen = {0: np.zeros(fm, bool), 1: np.zeros(ft, bool)}
         for st, out_slice, out_block, base_i, ni, base_j, nj in rows:
             assert not seen[st][base_j:base_j + nj * 1024].any() and not seen[st][base_i:base_i + ni * 1024].any()
             seen[st][base_j:base_j + nj * 1024] = True
             seen[st][base_i:base_i + ni * 1024] = True
+            blk = (r * tb + out_block) if (st == 1 or not (exchange or world > 1)) else out_slice * tb + out_block
+            blk_real = real[blk * 1024:(blk + 1) * 1024]
+            for base, cnt in ((base_j, nj), (base_i, ni)):                   # a row's cells of real slots all have their writer
+                w = sets[st][base:base + cnt * 1024].reshape(cnt, 1024)
+                nd = needs[st][base:base + cnt * 1024].reshape(cnt, 1024)
+                assert (w[:, blk_real] == 1).all() and not nd[:, ~blk_real].any()
             tot = vals[st][base_j:base_j + nj * 1024].reshape(nj, 1024).sum(0) + vals[st][base_i:base_i + ni * 1024].reshape(ni, 1024).sum(0)
             if exchange or world > 1:
                 if st == 1:
@@ -239,8 +280,10 @@ def test_pair_symmetric_layout_is_complete_and_collision_free(mh, n, world, spli
                 own[0, out_block * 1024:(out_block + 1) * 1024] += tot
         for st in (0, 1):
             assert seen[st].all()                                          # the tables account for every row
-    assert (count == 1).all(), np.unique(count)
-    assert ((own + recv) == slots).all()
+    assert (count <= 1).all(), np.unique(count)
+    real_cells = real.reshape(-1, G).any(1)
+    assert (count[np.ix_(real_cells, real_cells)] == 1).all()
+    assert ((own + recv).reshape(-1)[real] == n).all()
 
 
 def test_layout_query_rejects_bad_arguments(mh):

@@ -176,13 +176,14 @@ def test_bench_py_with_several_ranks(gpu, world, n):
     # a first real multi-GPU run must explain itself: both collectives and the compute stream's waits for them, event-timed
     # on rank 0's streams; the one-sided (all-gather only) plan timed beside the half-ring one; the other sizes
     ex = d["exchange"]
-    assert ex["steps_profiled"] == 10 and abs(ex["launches_per_step"] - 3) < 1e-9
+    # three force launches per step, two when the tuned split leaves one part of the own-slice triangle empty
+    assert ex["steps_profiled"] == 10 and abs(ex["launches_per_step"] - (2 if d["tuned"]["tri_first_pct"] in (0, 100) else 3)) < 1e-9
     for k in ("reduce_scatter_ms_avg", "all_gather_ms_avg", "compute_stream_step_ms_avg", "ms_per_step_with_profiling"):
         assert ex[k] > 0, (k, ex)
     for k in ("compute_wait_gather_ms_avg", "compute_wait_reduce_ms_avg"):
         assert 0 <= ex[k] <= ex["compute_stream_step_ms_avg"], (k, ex)
     assert abs(ex["compute_wait_ms_avg"] - ex["compute_wait_gather_ms_avg"] - ex["compute_wait_reduce_ms_avg"]) < 1e-6
-    assert all(v > 0 for v in ex["force_ms_avg"].values())
+    assert sum(v > 0 for v in ex["force_ms_avg"].values()) >= 2 and ex["force_ms_avg"]["rectangles"] > 0
     assert ex["payload_bytes_per_rank"]["all_gather_out"] == world * ex["payload_bytes_per_rank"]["all_gather_in"]
     alt = d["one_sided_plan"]
     assert alt["ms_per_step"] > 0 and abs(alt["half_ring_speedup"] - alt["ms_per_step"] / d["ms_per_step"]) < 1e-9
