@@ -214,6 +214,10 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  *                    swaps + DPP), 1 = through LDS (fewer VALU instructions).  -1 (default) = the plan's own choice
  *   "sym_waves"      variant 8: waves per workgroup, 4 or 8; 0 = auto (8, with `split` 8, on one GPU below
  *                    45 000 bodies: a short launch drains faster; 4 otherwise)
+ *   "pad_aware"      variant 8: 1 (default) = the zero-mass padding slots that fill a slice up to whole blocks of 1024 are
+ *                    not walked: the emptier block of a pair goes on the walked (i) side and its items end at its last
+ *                    real body; 0 = every block as if full (kept for the A/B: -3 % at N = 30 000, -4 % for a rank of 8
+ *                    at N = 200 000)
  *   "xcd_order"      variant 8: 0 (default) = j-major item order (round-robin dispatch then gives XCD x the i
  *                    blocks x mod 8 of every j block); 1 = one contiguous run of items per XCD (measured:
  *                    more L2 misses, same time; kept for the comparison)

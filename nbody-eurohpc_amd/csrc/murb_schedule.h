@@ -75,14 +75,14 @@ struct SymFill {
         return left <= 1 ? 1 : (left >= MURB_SLICE_ALIGN ? MURB_SLICE_ALIGN : left);
     }
 };
-inline SymFill sym_fill(unsigned long n, int world)
+inline SymFill sym_fill(unsigned long n, int world, bool aware = true)
 {
     SymFill f;
     f.tb = (int)(slice_slots(n, world) / MURB_SLICE_ALIGN);
     for (int s = 0; s < world; ++s) {
         unsigned long first, count;
         partition(n, world, s, &first, &count);
-        f.count.push_back((int)count);
+        f.count.push_back(aware ? (int)count : f.tb * MURB_SLICE_ALIGN);   // not aware ("pad_aware" 0): every block counts as full
     }
     return f;
 }

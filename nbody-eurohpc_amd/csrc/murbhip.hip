@@ -97,6 +97,7 @@ struct Shard {
     int sym_split = 0, sym_waves = 0, sym_taper = -1, sym_diag_tri = -1;   // what the table was built for
     int sym_red = 0;                              // i-side reduction of the plan (kernel template parameter)
     long sym_pass_mb = -1;                        // "sym_pass_mb" the passes were cut for
+    int sym_pad_aware = -1;                       // ... and "pad_aware"
     int sym_xcd_order = -1;                       // ... and the item order ("xcd_order")
     int sym_tri_first = -1, sym_overlap = -1;     // ... and the launch boundaries inside the own-slice triangle ("tri_first_pct", "overlap")
     int sym_t1 = 0;                               // items of the triangle's first launch (exchange pipeline, overlap 1)
@@ -169,6 +170,7 @@ struct murbhip_ctx {
     int diag_tri = -1;        // ... diagonal blocks as triangular pieces (-1 = the plan's default)
     long sym_pass_mb = 0;     // ... one GPU: budget (MiB) for the partial rows of one pass; 0 = a quarter of the device memory
     int sym_red = -1;         // ... i-side reduction in registers (0) or through LDS (1) (-1 = the plan's default)
+    int pad_aware = 1;        // ... 1: padding slots are not walked (murb_schedule.h, sym_orient); 0: every block as if full (A/B)
     int cu_reserve = 0;       // CUs masked out of the compute streams (left free for the collectives' kernels)
     int solo_shard = -1;      // >= 0: only this shard computes (timing aid: one rank's isolated timeline
                               // when W shards share one GPU; results are then meaningless)
@@ -853,6 +855,7 @@ bool sym_schedule_stale(const murbhip_ctx* c, const Shard& sh, const Plan& p)
     const bool exchange_mode = c->world > 1 || c->force_exchange;
     return !(sh.sym_items && sh.sym_split == p.split && sh.sym_waves == p.waves && sh.sym_taper == p.taper && sh.sym_diag_tri == (int)p.diag_tri &&
              sh.sym_exchange_mode == exchange_mode && sh.sym_xcd_order == c->xcd_order && sh.sym_pass_mb == c->sym_pass_mb &&
+             sh.sym_pad_aware == c->pad_aware &&
              (!exchange_mode || (sh.sym_tri_first == c->tri_first_pct && sh.sym_overlap == c->overlap)));
 }
 
@@ -868,7 +871,7 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
     sh.sym_bytes = 0;
 
     SymHostLayout L;
-    plan_sym_layout(c->world, sh.rank, sym_fill(c->n, c->world), p.split, p.waves, p.taper, p.diag_tri, exchange_mode,
+    plan_sym_layout(c->world, sh.rank, sym_fill(c->n, c->world, c->pad_aware != 0), p.split, p.waves, p.taper, p.diag_tri, exchange_mode,
                     c->overlap, c->tri_first_pct, c->xcd_order != 0, sym_pass_budget(c) / (3 * sizeof(float)), L);
     if (!exchange_mode && L.passes.size() == 1 && (int)L.table_main.size() != (int)(c->slots / MURB_SYM_BLOCK))
         return MURBHIP_E_STATE;   // the fused row sum + integrate walks every block
@@ -876,6 +879,7 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
     RC_TRY(upload_sym_set(sh, sh.sym_main, L.table_main, L.floats_main));
     sh.sym_main.passes = L.passes;
     sh.sym_pass_mb = c->sym_pass_mb;
+    sh.sym_pad_aware = c->pad_aware;
     if (L.passes.size() > 1 && !sh.sym_acc64) {
         HIP_TRY(hipMalloc((void**)&sh.sym_acc64, 3 * c->slots * sizeof(double)));
         sh.bytes += 3 * c->slots * sizeof(double);
@@ -1819,6 +1823,7 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     if (k == "variant") { if (value < 0 || value > kNumVariants) return MURBHIP_E_INVALID; c->variant = (int)value; }
     else if (k == "jsplit") { if (value < 0 || value > kMaxParts / 2) return MURBHIP_E_INVALID; c->jsplit = (int)value; }
     else if (k == "xcd_order") c->xcd_order = value ? 1 : 0;
+    else if (k == "pad_aware") c->pad_aware = value ? 1 : 0;
     else if (k == "tri_first_pct") { if (value < 0 || value > 100) return MURBHIP_E_INVALID; c->tri_first_pct = (int)value; }
     else if (k == "taper") { if (value < -1 || value > 100) return MURBHIP_E_INVALID; c->taper = (int)value; }
     else if (k == "sym_pass_mb") { if (value < 0) return MURBHIP_E_INVALID; c->sym_pass_mb = value; }
