@@ -138,6 +138,20 @@ int murbhip_destroy(murbhip_ctx* ctx);
 int murbhip_upload(murbhip_ctx* ctx, const float* qx, const float* qy, const float* qz, const float* vx,
                    const float* vy, const float* vz, const float* m);
 
+/* Initial conditions generated ON THE DEVICE, instead of murbhip_upload: the n bodies of the reference's scheme "galaxy"
+ * (Bodies::initGalaxy, src/common/core/Bodies.cpp:158-214) or "random" (initRandomly, :217-257) for srand(seed), bit-identical
+ * to what the reference's host code computes on this machine — glibc's rand() sequence (jump-ahead on the linear TYPE_3
+ * generator), the float/double mix of the reference's expressions as compiled with its flags, and glibc's sincosf
+ * (csrc/murb_init.h).  Every shard fills its own copy of the replicated records; nothing crosses PCIe.  The host-side SIMD
+ * padding bodies of the reference (Bodies.cpp:201-213) draw from rand() AFTER the n bodies and never reach the device.
+ * Option "init_libm_fma": which build of glibc's sincosf to reproduce (1 = the -mfma one glibc selects on CPUs with FMA and
+ * AVX2, 0 = the SSE2 one; -1, default = what this host's libm would pick). */
+int murbhip_init_bodies(murbhip_ctx* ctx, const char* scheme, unsigned long seed);
+
+/* Masses (and, after murbhip_init_bodies, radii; `r` may be NULL) of all n bodies, device -> host: what a host mirror
+ * needs to complete its dataSoA when the bodies were created on the device (rank mode: own slice only). */
+int murbhip_download_mass(murbhip_ctx* ctx, float* m, float* r);
+
 /* Device -> host SoA of all n bodies; waits for enqueued steps first.  This is the lazy D2H behind
  * CUDABodies::getDataSoA() (CUDABodies.cu:64-93).  Any pointer may be NULL.  In rank mode velocities
  * are only known for the caller's own slice: entries of other ranks are left untouched. */

@@ -39,6 +39,7 @@
 #include <vector>
 
 #include "../../include/murbhip.h"
+#include "murb_init.h"
 #include "murb_kernels_sym.h"
 #include "murb_rccl.h"
 #include "murb_schedule.h"
@@ -90,6 +91,7 @@ struct Shard {
     float* acc_out = nullptr;
     float* phi_out = nullptr;    // murbhip_energy's potential sweep (same shape as acc_out), allocated on first use
     float* mass = nullptr;       // masses of the local slice as uploaded (metrics)
+    float* radius = nullptr;     // radii of the local slice: only after murbhip_init_bodies (the host never sent them)
     double* metrics = nullptr;   // block sums of murb_metrics_kernel
     // pair-symmetric kernel: item table and partial-row layouts (built by build_sym_schedule for one plan)
     MurbSymItem* sym_items = nullptr;
@@ -170,6 +172,7 @@ struct murbhip_ctx {
     int diag_tri = -1;        // ... diagonal blocks as triangular pieces (-1 = the plan's default)
     long sym_pass_mb = 0;     // ... one GPU: budget (MiB) for the partial rows of one pass; 0 = a quarter of the device memory
     int sym_red = -1;         // ... i-side reduction in registers (0) or through LDS (1) (-1 = the plan's default)
+    int init_libm_fma = -1;   // murbhip_init_bodies: which build of glibc's sincosf to reproduce (-1 = what this host's libm picks)
     int pad_aware = 1;        // ... 1: padding slots are not walked (murb_schedule.h, sym_orient); 0: every block as if full (A/B)
     int cu_reserve = 0;       // CUs masked out of the compute streams (left free for the collectives' kernels)
     int solo_shard = -1;      // >= 0: only this shard computes (timing aid: one rank's isolated timeline
@@ -1491,7 +1494,7 @@ int murbhip_destroy(murbhip_ctx* c)
         if (sh.ev_gathered) hipEventDestroy(sh.ev_gathered);
         if (sh.compute) hipStreamDestroy(sh.compute);
         if (sh.comm) hipStreamDestroy(sh.comm);
-        hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out); hipFree(sh.phi_out); hipFree(sh.mass); hipFree(sh.metrics);
+        hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out); hipFree(sh.phi_out); hipFree(sh.mass); hipFree(sh.radius); hipFree(sh.metrics);
         hipFree(sh.sym_items); free_sym_set(sh.sym_main); free_sym_set(sh.sym_tri);
         hipFree(sh.sym_send); hipFree(sh.sym_recv); hipFree(sh.sym_tri_acc); hipFree(sh.sym_acc64);
         if (sh.ev_rowsum) hipEventDestroy(sh.ev_rowsum);
@@ -1534,6 +1537,103 @@ int murbhip_upload(murbhip_ctx* c, const float* qx, const float* qy, const float
     c->uploaded = true;
     c->lf_half = false;
     c->acc_current = false;
+    return 0;
+}
+
+namespace {
+// The 61 generator words around the first value rand() returns after srand(seed): glibc's srandom_r / random_r for the
+// default TYPE_3 state (stdlib/random_r.c: 31 words from a 16807 Lehmer sequence, taps 3 apart, 310 outputs discarded).
+MurbRandBase rand_base_words(unsigned int seed)
+{
+    int32_t st[MURB_RAND_DEG];
+    int32_t word = seed == 0 ? 1 : (int32_t)seed;
+    st[0] = word;
+    for (int i = 1; i < MURB_RAND_DEG; ++i) {
+        const long hi = word / 127773, lo = word % 127773;
+        word = (int32_t)(16807 * lo - 2836 * hi);
+        if (word < 0) word += 2147483647;
+        st[i] = word;
+    }
+    const int discard = 10 * MURB_RAND_DEG, first = discard - MURB_RAND_DEG, count = 2 * MURB_RAND_DEG - 1;
+    MurbRandBase b{};
+    int f = 3, r = 0;
+    for (int t = 0; t < first + count; ++t) {
+        const uint32_t val = (uint32_t)st[f] + (uint32_t)st[r];
+        st[f] = (int32_t)val;
+        if (t >= first) b.u[t - first] = val;
+        f = (f + 1) % MURB_RAND_DEG;
+        r = (r + 1) % MURB_RAND_DEG;
+    }
+    return b;
+}
+}  // namespace
+
+int murbhip_init_bodies(murbhip_ctx* c, const char* scheme, unsigned long seed)
+{
+    if (!c || !scheme) return MURBHIP_E_INVALID;
+    const std::string sc(scheme);
+    const bool galaxy = sc == "galaxy";
+    if (!galaxy && sc != "random") return MURBHIP_E_INVALID;
+    RC_TRY(murbhip_sync(c));
+    const unsigned long draws = galaxy ? 4ul * (c->n - 1) : 7ul * c->n;
+    const MurbRandBase base = rand_base_words((unsigned int)seed);
+    // glibc picks its FMA build of sincosf on CPUs with FMA and AVX2 (sysdeps/x86_64/fpu/multiarch/ifunc-fma.h)
+    const bool fma = c->init_libm_fma >= 0 ? c->init_libm_fma != 0 : (__builtin_cpu_supports("fma") && __builtin_cpu_supports("avx2"));
+    for (Shard& sh : c->shards) {
+        HIP_TRY(hipSetDevice(sh.device));
+        if (!sh.mass) { HIP_TRY(hipMalloc((void**)&sh.mass, c->slice * sizeof(float))); sh.bytes += c->slice * sizeof(float); }
+        if (!sh.radius) { HIP_TRY(hipMalloc((void**)&sh.radius, c->slice * sizeof(float))); sh.bytes += c->slice * sizeof(float); }
+        unsigned int* d_draws = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_draws, std::max(draws, 1ul) * sizeof(unsigned int)));
+        int rc = 0;
+        const unsigned long chunks = (draws + MURB_RAND_CHUNK - 1) / MURB_RAND_CHUNK;
+        if (chunks) hipLaunchKernelGGL(murb_rand_fill_kernel, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, sh.compute, base, draws, d_draws);
+        rc = hip_rc(hipGetLastError());
+        // padding slots: position 0, mass 0, like the records murbhip_upload packs
+        if (!rc) rc = hip_rc(hipMemsetAsync(sh.rec[0], 0, c->slots * sizeof(float4), sh.compute));
+        if (!rc) rc = hip_rc(hipMemsetAsync(sh.rec[1], 0, c->slots * sizeof(float4), sh.compute));
+        if (!rc) rc = hip_rc(hipMemsetAsync(sh.vel, 0, c->slice * sizeof(float4), sh.compute));
+        if (!rc) rc = hip_rc(hipMemsetAsync(sh.mass, 0, c->slice * sizeof(float), sh.compute));
+        if (!rc) rc = hip_rc(hipMemsetAsync(sh.radius, 0, c->slice * sizeof(float), sh.compute));
+        if (!rc) {
+            MurbInitArgs a{};
+            a.draws = d_draws; a.rec0 = sh.rec[0]; a.rec1 = sh.rec[1]; a.vel = sh.vel; a.mass = sh.mass; a.radius = sh.radius;
+            a.n = c->n; a.world = (unsigned int)c->world; a.rank = (unsigned int)sh.rank; a.slice = (unsigned int)c->slice; a.g = c->g;
+            const dim3 grid((unsigned)((c->n + 255) / 256));
+            if (!galaxy) hipLaunchKernelGGL(murb_init_random_kernel, grid, dim3(256), 0, sh.compute, a);
+            else if (fma) hipLaunchKernelGGL((murb_init_galaxy_kernel<true>), grid, dim3(256), 0, sh.compute, a);
+            else hipLaunchKernelGGL((murb_init_galaxy_kernel<false>), grid, dim3(256), 0, sh.compute, a);
+            rc = hip_rc(hipGetLastError());
+        }
+        const int rs = hip_rc(hipStreamSynchronize(sh.compute));
+        hipFree(d_draws);
+        if (rc || rs) return rc ? rc : rs;
+        sh.prof_used = 0;
+    }
+    c->cur = 0;
+    c->gather_pending = false;
+    c->uploaded = true;
+    c->lf_half = false;
+    c->acc_current = false;
+    return 0;
+}
+
+int murbhip_download_mass(murbhip_ctx* c, float* m, float* r)
+{
+    if (!c || !m) return MURBHIP_E_INVALID;
+    if (!c->uploaded) return MURBHIP_E_STATE;
+    RC_TRY(murbhip_sync(c));
+    std::vector<float> buf(c->slice);
+    for (Shard& sh : c->shards) {
+        HIP_TRY(hipSetDevice(sh.device));
+        HIP_TRY(hipMemcpy(buf.data(), sh.mass, buf.size() * sizeof(float), hipMemcpyDeviceToHost));
+        std::memcpy(m + sh.first, buf.data(), sh.count * sizeof(float));
+        if (r) {
+            if (!sh.radius) return MURBHIP_E_STATE;   // radii exist on the device only after murbhip_init_bodies
+            HIP_TRY(hipMemcpy(buf.data(), sh.radius, buf.size() * sizeof(float), hipMemcpyDeviceToHost));
+            std::memcpy(r + sh.first, buf.data(), sh.count * sizeof(float));
+        }
+    }
     return 0;
 }
 
@@ -1824,6 +1924,7 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     else if (k == "jsplit") { if (value < 0 || value > kMaxParts / 2) return MURBHIP_E_INVALID; c->jsplit = (int)value; }
     else if (k == "xcd_order") c->xcd_order = value ? 1 : 0;
     else if (k == "pad_aware") c->pad_aware = value ? 1 : 0;
+    else if (k == "init_libm_fma") { if (value < -1 || value > 1) return MURBHIP_E_INVALID; c->init_libm_fma = (int)value; }
     else if (k == "tri_first_pct") { if (value < 0 || value > 100) return MURBHIP_E_INVALID; c->tri_first_pct = (int)value; }
     else if (k == "taper") { if (value < -1 || value > 100) return MURBHIP_E_INVALID; c->taper = (int)value; }
     else if (k == "sym_pass_mb") { if (value < 0) return MURBHIP_E_INVALID; c->sym_pass_mb = value; }

@@ -138,6 +138,12 @@ void murbhost_sim_step(void *p, int iterations)
     for (int i = 0; i < iterations; ++i) h->sim->computeOneIteration();
     h->sim->synchronize();
 }
+// HIPBodies::initOnDevice with the scheme the simulation was created with
+void murbhost_sim_init_on_device(void *p, unsigned long seed)
+{
+    auto *h = static_cast<Sim *>(p);
+    std::dynamic_pointer_cast<HIPBodies<float>>(h->sim->getBodies())->initOnDevice(h->scheme, seed);
+}
 unsigned long murbhost_sim_n(void *p) { return static_cast<Sim *>(p)->sim->getBodies()->getN(); }
 float murbhost_sim_flops_per_ite(void *p) { return static_cast<Sim *>(p)->sim->getFlopsPerIte(); }
 float murbhost_sim_allocated_bytes(void *p) { return static_cast<Sim *>(p)->sim->getAllocatedBytes(); }

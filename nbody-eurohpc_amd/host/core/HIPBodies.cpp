@@ -41,6 +41,18 @@ template <typename T> void HIPBodies<T>::bindDevice(T soft, T G, const std::vect
     dataOnCPU = true;
 }
 
+template <typename T> void HIPBodies<T>::initOnDevice(const std::string &scheme, const unsigned long randInit)
+{
+    if (!ctx) {
+        std::fprintf(stderr, "HIPBodies::initOnDevice needs a bound device (construct the simulation first)\n");
+        std::exit(EXIT_FAILURE);
+    }
+    murbhipCheck(murbhip_init_bodies(ctx, scheme.c_str(), randInit), "murbhip_init_bodies");
+    dataSoA_t<T> &d = this->dataSoA;   // masses and radii are not part of the lazy copy: fetch them once
+    murbhipCheck(murbhip_download_mass(ctx, d.m.data(), d.r.data()), "murbhip_download_mass");
+    dataOnCPU = false;
+}
+
 template <typename T> const dataSoA_t<T> &HIPBodies<T>::getDataSoA() const
 {
     if (!dataOnCPU && ctx) {

@@ -34,6 +34,11 @@ template <typename T> class HIPBodies : public Bodies<T> {
     void bindDevice(T soft, T G, const std::vector<int> &devices = {0}, int exchange = 1);
     murbhip_ctx *getContext() const { return ctx; }
 
+    // The initial conditions again, this time generated ON THE DEVICE (murbhip_init_bodies: bit-identical to what the
+    // constructor computed on the host for the same scheme and seed) — the bodies of a run then never cross PCIe.  Needs a
+    // bound device; the host copy is refreshed lazily like after a step.  "galaxy" and "random" only.
+    void initOnDevice(const std::string &scheme = "galaxy", const unsigned long randInit = 0);
+
     void invalidateDataSoA() { dataOnCPU = false; }
     const dataSoA_t<T> &getDataSoA() const override;
     const std::vector<dataAoS_t<T>> &getDataAoS() const override;

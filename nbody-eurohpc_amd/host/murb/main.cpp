@@ -39,6 +39,7 @@ std::string BodiesScheme = "galaxy";
 bool ShowGFlops = false;
 int NDevices = 0;        // --ngpu, hip+tile+multi only (0 = all visible)
 bool FreeRunning = false;   // --free: sync once at the end instead of once per iteration
+bool DeviceInit = false;    // --dinit: generate the initial conditions on the device (bit-identical to the host's)
 std::string MetricsFile;    // --csv: where hip+tracking / hip+leapfrog save their history
 std::shared_ptr<SimulationHistory<double>> History;
 
@@ -77,6 +78,7 @@ static std::vector<Option> optionTable()
         {"-gf", "", false, "display the number of GFlop/s."},
         {"-ngpu", "nGpus", false, "number of GPUs for hip+tile+multi (default: all visible)."},
         {"-free", "", false, "free-running timing: one device sync at the end, not one per iteration."},
+        {"-dinit", "", false, "generate the initial conditions on the device (same bodies, bit for bit)."},
         {"-csv", "file", false, "hip+tracking / hip+leapfrog: save the metrics history as CSV."},
     };
 }
@@ -103,6 +105,7 @@ static void argsReader(int argc, char **argv)
     VisuEnable = !given("-nv");
     ShowGFlops = given("-gf");
     FreeRunning = given("-free");
+    DeviceInit = given("-dinit");
     if (given("-dt")) Dt = stof(reader.get_argument("-dt"));
     if (given("-im")) ImplTag = reader.get_argument("-im");
     if (given("s")) BodiesScheme = reader.get_argument("s");
@@ -161,6 +164,13 @@ int main(int argc, char **argv)
 {
     argsReader(argc, argv);
     SimulationNBodyHIP<float> *simu = createImplem<float>();
+    if (DeviceInit) {
+        if (BodiesScheme != "galaxy" && BodiesScheme != "random") {
+            std::cout << "--dinit supports the \"galaxy\" and \"random\" schemes... exiting." << std::endl;
+            exit(-1);
+        }
+        std::dynamic_pointer_cast<HIPBodies<float>>(simu->getBodies())->initOnDevice(BodiesScheme, 0);
+    }
     NBodies = simu->getBodies()->getN();
     const float Mbytes = simu->getAllocatedBytes() / 1024.f / 1024.f;
 

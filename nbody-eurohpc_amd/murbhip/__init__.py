@@ -57,6 +57,8 @@ def lib():
                                           C.c_int, C.c_void_p]
         L.murbhip_destroy.argtypes = [C.c_void_p]
         L.murbhip_upload.argtypes = [C.c_void_p] + [_fp] * 7
+        L.murbhip_init_bodies.argtypes = [C.c_void_p, C.c_char_p, C.c_ulong]
+        L.murbhip_download_mass.argtypes = [C.c_void_p, _fp, _fp]
         L.murbhip_download_state.argtypes = [C.c_void_p] + [_fp] * 6
         L.murbhip_download_acc.argtypes = [C.c_void_p] + [_fp] * 3
         L.murbhip_compute_acc.argtypes = [C.c_void_p]
@@ -75,7 +77,7 @@ def lib():
 EXPORTS = ("murbhip_version murbhip_error_string murbhip_partition murbhip_slice_slots murbhip_slot_of_body "
            "murbhip_schedule_items murbhip_schedule_layout "
            "murbhip_device_count murbhip_create murbhip_create_sharded murbhip_unique_id murbhip_create_rank "
-           "murbhip_destroy murbhip_upload murbhip_download_state murbhip_download_acc murbhip_compute_acc "
+           "murbhip_destroy murbhip_upload murbhip_init_bodies murbhip_download_mass murbhip_download_state murbhip_download_acc murbhip_compute_acc "
            "murbhip_step murbhip_steps murbhip_integrate_host_acc murbhip_sync murbhip_energy murbhip_moments murbhip_set_option "
            "murbhip_get_info").split()
 
@@ -177,6 +179,16 @@ class Simulation:
                 raise ValueError("state arrays shorter than n")
         _check(lib().murbhip_upload(self._h, *[_ptr(x) for x in a]), "murbhip_upload")
 
+    def init_bodies(self, scheme="galaxy", seed=0):
+        """Initial conditions generated on the device (include/murbhip.h: murbhip_init_bodies)."""
+        _check(lib().murbhip_init_bodies(self._h, scheme.encode(), seed), "murbhip_init_bodies")
+
+    def masses(self, with_radii=False):
+        m = np.zeros(self.n, np.float32)
+        r = np.zeros(self.n, np.float32) if with_radii else None
+        _check(lib().murbhip_download_mass(self._h, _ptr(m), _ptr(r) if with_radii else None), "murbhip_download_mass")
+        return (m, r) if with_radii else m
+
     def state(self):
         out = {k: np.zeros(self.n, np.float32) for k in ("qx", "qy", "qz", "vx", "vy", "vz")}
         _check(lib().murbhip_download_state(self._h, *[_ptr(out[k]) for k in ("qx", "qy", "qz", "vx", "vy", "vz")]),
@@ -272,6 +284,7 @@ def host_lib():
                                           C.c_int]
         H.murbhost_sim_destroy.argtypes = [C.c_void_p]
         H.murbhost_sim_step.argtypes = [C.c_void_p, C.c_int]
+        H.murbhost_sim_init_on_device.argtypes = [C.c_void_p, C.c_ulong]
         H.murbhost_sim_n.restype = C.c_ulong
         H.murbhost_sim_n.argtypes = [C.c_void_p]
         H.murbhost_sim_flops_per_ite.restype = C.c_float
@@ -353,6 +366,10 @@ class HostSim:
 
     def step(self, iterations=1):
         self.H.murbhost_sim_step(self.h, iterations)
+
+    def init_on_device(self, seed=0):
+        """HIPBodies::initOnDevice: the same initial conditions, generated on the device."""
+        self.H.murbhost_sim_init_on_device(self.h, seed)
 
     def state(self):
         pad = 0

@@ -276,3 +276,83 @@ def ref_integrate(n, scheme, acc, dt, steps):
     ax, ay, az = (np.ascontiguousarray(a, np.float32) for a in acc)
     ref_lib().murbref_integrate(n, scheme.encode(), ax, ay, az, dt, steps, *[out[k] for k in FIELDS[:6]])
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Initial conditions restated in numpy with every rounding spelled out (checker for csrc/murb_init.h, the on-device
+# initialisation).  rand() comes from this host's libc; sincosf is glibc 2.35's algorithm (sysdeps/ieee754/flt-32/
+# s_sincosf.{c,h}, the ARM optimized-routines sincosf) in its NON-FMA (SSE2) build: numpy rounds every product and sum on
+# its own, which is exactly that build.  (The -mfma build glibc selects on CPUs with FMA and AVX2 differs from it in the
+# last bit of a few results per million; the device's rendering of that one is checked against the host's libm itself.)
+def glibc_rand_draws(seed, count):
+    """The first `count` values of rand() after srand(seed), from this process's libc."""
+    libc = C.CDLL(None)
+    libc.rand.restype = C.c_int
+    libc.srand(C.c_uint(seed))
+    return np.fromiter((libc.rand() for _ in range(count)), dtype=np.int64, count=count)
+
+
+def sincosf_glibc_sse2(y):
+    """(sin, cos) of float32 values |y| < 120 by glibc's sincosf, SSE2 build: float64 arithmetic, one rounding per operation."""
+    y = np.asarray(y, np.float32)
+    x = y.astype(np.float64)
+    top = (y.view(np.uint32) >> 20) & 0x7FF
+    assert (top < 0x42F).all()
+    hpi_inv, hpi = float.fromhex("0x1.45f306dc9c883p+23"), float.fromhex("0x1.921fb54442d18p+0")
+    r = x * hpi_inv
+    n = ((r.astype(np.int32).astype(np.int64) + 0x800000) >> 24).astype(np.int64)
+    medium = top >= 0x3F4
+    n = np.where(medium, n, 0)
+    xr = np.where(medium, x - n.astype(np.float64) * hpi, x)
+    s = np.where(medium & (((n & 3) == 1) | ((n & 3) == 2)), -1.0, 1.0)
+    sg = np.where(medium & ((n & 2) != 0), -1.0, 1.0)
+    c0, c1, c2 = sg * 1.0, sg * float.fromhex("-0x1.ffffffd0c621cp-2"), sg * float.fromhex("0x1.55553e1068f19p-5")
+    c3, c4 = sg * float.fromhex("-0x1.6c087e89a359dp-10"), sg * float.fromhex("0x1.99343027bf8c3p-16")
+    s1, s2, s3 = float.fromhex("-0x1.555545995a603p-3"), float.fromhex("0x1.1107605230bc4p-7"), float.fromhex("-0x1.994eb3774cf24p-13")
+    xx, x2 = xr * s, xr * xr
+    x3, x4 = x2 * xx, x2 * x2
+    c2p, s1p, c1p = x2 * c4 + c3, x2 * s3 + s2, x2 * c1 + c0
+    x5, x6 = x2 * x3, x2 * x4
+    sv = ((x3 * s1 + xx) + s1p * x5).astype(np.float32)
+    cv = ((x4 * c2 + c1p) + c2p * x6).astype(np.float32)
+    odd = (n & 1) == 1
+    sin, cos = np.where(odd, cv, sv), np.where(odd, sv, cv)
+    tiny = top < 0x398
+    return np.where(tiny, y, sin).astype(np.float32), np.where(tiny, np.float32(1.0), cos).astype(np.float32)
+
+
+def init_galaxy_spelled_out(n, seed=0):
+    """Bodies::initGalaxy (Bodies.cpp:158-214) as the reference's flags compile it (operation by operation, read off the
+    object code), with sincosf_glibc_sse2: what the device produces under "init_libm_fma" = 0."""
+    f32, f64 = np.float32, np.float64
+    y = glibc_rand_draws(seed, 4 * (n - 1)).reshape(n - 1, 4)
+    k31 = f32(2.0 ** -31)
+    frac_up = y[:, 0].astype(f32) * k31
+    down = lambda col: (2147483647 - y[:, col]).astype(f32) * k31   # noqa: E731
+    m = (frac_up.astype(f64) * 5e20).astype(f32)
+    r = (m.astype(f64) * 2.5e-15).astype(f32)
+    two_pi = float.fromhex("0x1.921fb54442d18p+2")
+    sh, ch = sincosf_glibc_sse2((down(1).astype(f64) * two_pi).astype(f32))
+    sv, cv = sincosf_glibc_sse2((down(2).astype(f64) * two_pi).astype(f32))
+    dist = ((down(3).astype(f64) + 1.0) * 1.0e8).astype(f32)
+    qx, qy, qz = (sh * cv) * dist, sv * dist, (cv * ch) * dist
+    vx, vy = (qy.astype(f64) * 4.0e-6).astype(f32), ((-qx).astype(f64) * 4.0e-6).astype(f32)
+    z = np.zeros(1, f32)
+    cat = lambda first, rest: np.concatenate([np.asarray([first], f32), rest.astype(f32)])   # noqa: E731
+    return {"m": cat(2.0e24, m), "r": cat(0, r), "qx": cat(0, qx), "qy": cat(0, qy), "qz": cat(0, qz), "vx": cat(0, vx), "vy": cat(0, vy),
+            "vz": np.zeros(n, f32) + z}
+
+
+def init_random_spelled_out(n, seed=0):
+    """Bodies::initRandomly (Bodies.cpp:217-257) as compiled: mass draw, then the six draws of the box (three of them
+    folded by -ffast-math into a single float multiply)."""
+    f32, f64 = np.float32, np.float64
+    y = glibc_rand_draws(seed, 7 * n).reshape(n, 7)
+    m = ((y[:, 0].astype(f32) * f32(2.0 ** -31)).astype(f64) * 5.0e21).astype(f32)
+    r = (m.astype(f64) * 0.5e-14).astype(f32)
+    fc = lambda col: (y[:, col] - 0x3FFFFFFF).astype(f32)   # noqa: E731
+    k = lambda bits: np.array([bits], np.uint32).view(f32)[0]   # noqa: E731
+    kv = k(0x33C80000)
+    return {"m": m, "r": r, "qx": fc(1) * k(0x3F1E8C61), "qy": fc(2) * k(0x3EEE6B28),
+            "qz": ((fc(3) * f32(2.0 ** -30)).astype(f64) * 5.0e8 - 1.0e9).astype(f32),
+            "vx": fc(4) * kv, "vy": fc(5) * kv, "vz": fc(6) * kv}

@@ -1025,3 +1025,107 @@ def test_long_sharded_runs_are_bit_reproducible(gpu, O, shards, variant, overlap
     for k in out[0]:
         assert np.array_equal(bits(out[0][k]), bits(out[1][k])), k
     assert all(np.isfinite(out[0][k]).all() for k in out[0])
+
+
+# ---------------------------------------------------------------------------------------------------
+# initial conditions generated ON THE DEVICE (csrc/murb_init.h)
+
+@pytest.mark.parametrize("scheme,n,seed,devices", [
+    ("galaxy", 4096, 0, [0]), ("galaxy", 30000, 0, [0]), ("galaxy", 200000, 0, [0]), ("galaxy", 2049, 7, [0]), ("galaxy", 1, 0, [0]),
+    ("galaxy", 1000000, 0, [0]), ("galaxy", 60001, 123456789, [0, 0, 0]), ("random", 2049, 0, [0]), ("random", 30000, 5, [0]),
+    ("random", 12001, 1, [0, 0]), ("galaxy", 250, 0, [0]),
+])
+def test_device_initial_conditions_bit_identical_to_host(gpu, scheme, n, seed, devices):
+    """murbhip_init_bodies against the product's host initialisation (host/core/Bodies.cpp, bit-identical to the compiled
+    reference: tests/test_abi_and_host.py): every one of the eight arrays bit for bit — glibc's rand() sequence by
+    jump-ahead (draws up to 4 million deep), the compiled float/double mix, glibc's sincosf — on one GPU and over shards."""
+    want = gpu.init_bodies(n, scheme, seed)
+    kw = {"devices": devices} if len(devices) > 1 else {}
+    with gpu.Simulation(n, soft=SOFT, **kw) as sim:
+        sim.init_bodies(scheme, seed)
+        got = sim.state()
+        got["m"], got["r"] = sim.masses(with_radii=True)
+    for k in ("m", "r", "qx", "qy", "qz", "vx", "vy", "vz"):
+        bad = np.flatnonzero(got[k].view(np.uint32) != want[k].view(np.uint32))
+        assert len(bad) == 0, (k, len(bad), bad[:5], got[k][bad[:5]], want[k][bad[:5]])
+
+
+def test_device_initial_conditions_run_like_uploaded_ones(gpu):
+    """A run started from device-made bodies is the run started from the host's: same records (G*m folded in the same
+    way), so the same bits after stepping."""
+    n = 30000
+    with gpu.Simulation(n, soft=SOFT) as a, gpu.Simulation(n, soft=SOFT) as b:
+        a.init_bodies("galaxy", 0)
+        b.upload(gpu.init_bodies(n, "galaxy", 0))
+        for sim in (a, b):
+            sim.steps(DT, 3)
+            sim.sync()
+        sa, sb = a.state(), b.state()
+        ea, eb = a.energy(), b.energy()
+    for k in ("qx", "qy", "qz", "vx", "vy", "vz"):
+        assert np.array_equal(sa[k].view(np.uint32), sb[k].view(np.uint32)), k
+    assert ea == eb
+
+
+def test_device_initial_conditions_sse2_libm_variant(gpu, O):
+    """The other build of glibc's sincosf (plain SSE2, what a CPU without FMA/AVX2 runs; "init_libm_fma" = 0) against the
+    numpy restatement that rounds every operation on its own: bit-identical.  And the two builds differ from each other
+    in at most a few last bits per hundred thousand bodies."""
+    n = 100000
+    want = O.init_galaxy_spelled_out(n, 0)
+    with gpu.Simulation(n, soft=SOFT) as sim:
+        sim.set_option("init_libm_fma", 0)
+        sim.init_bodies("galaxy", 0)
+        got = sim.state()
+        got["m"], got["r"] = sim.masses(with_radii=True)
+        sim.set_option("init_libm_fma", 1)
+        sim.init_bodies("galaxy", 0)
+        fma = sim.state()
+    for k in ("m", "r", "qx", "qy", "qz", "vx", "vy", "vz"):
+        assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), k
+    differ = sum(int((fma[k].view(np.uint32) != got[k].view(np.uint32)).sum()) for k in ("qx", "qy", "qz"))
+    assert differ <= 30, differ
+
+
+def test_device_initial_conditions_errors(gpu):
+    with gpu.Simulation(1000, soft=SOFT) as sim:
+        with pytest.raises(gpu.MurbHipError):
+            sim.init_bodies("spiral", 0)
+        with pytest.raises(gpu.MurbHipError):
+            sim.masses()                      # nothing uploaded or initialised yet
+        sim.upload(gpu.init_bodies(1000, "galaxy"))
+        with pytest.raises(gpu.MurbHipError):
+            sim.masses(with_radii=True)       # the host never sent radii
+        assert np.array_equal(sim.masses(), gpu.init_bodies(1000, "galaxy")["m"])
+
+
+@pytest.mark.parametrize("scheme,n,devices", [("galaxy", 6151, (0,)), ("random", 4100, (0, 0))])
+def test_plugin_bodies_initialised_on_the_device(gpu, scheme, n, devices):
+    """HIPBodies::initOnDevice through the mirrored plugin classes: getDataSoA() after it returns the bodies the constructor
+    made on the host, bit for bit (masses and radii included), and the run goes on from there."""
+    with gpu.HostSim(n, scheme, devices=devices, exchange="copy") as sim:
+        before = sim.state()
+        sim.init_on_device(0)
+        after = sim.state()
+        for k in gpu.FIELDS:
+            assert np.array_equal(before[k].view(np.uint32), after[k].view(np.uint32)), k
+        sim.step(2)
+        moved = sim.state()
+    with gpu.HostSim(n, scheme, devices=devices, exchange="copy") as ref:
+        ref.step(2)
+        want = ref.state()
+    for k in gpu.FIELDS:
+        assert np.array_equal(moved[k].view(np.uint32), want[k].view(np.uint32)), k
+
+
+def test_murb_hip_cli_device_init(gpu):
+    """`murb-hip --dinit`: the same run from bodies generated on the device (the banner and the final line are unchanged)."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "nbody-eurohpc_amd", "bin", "murb-hip")
+    r = subprocess.run([exe, "-n", "20000", "-i", "5", "--nv", "--im", "hip+tracking", "--dinit"], capture_output=True, text=True, timeout=300)
+    r0 = subprocess.run([exe, "-n", "20000", "-i", "5", "--nv", "--im", "hip+tracking"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r0.returncode == 0, (r.stderr, r0.stderr)
+    energy = [l for l in r.stdout.splitlines() if l.startswith("Energy at the first")]
+    assert energy and energy == [l for l in r0.stdout.splitlines() if l.startswith("Energy at the first")]
+    assert "Entire simulation took" in r.stdout

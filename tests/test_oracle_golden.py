@@ -166,3 +166,45 @@ def test_reference_cpu_optim_loses_far_pairs_in_the_random_scheme(O):
     s = O.init_bodies(30000, "galaxy")
     e = O.rel_err(O.accel_optim(s, SOFT), O.accel_f64(s, SOFT))
     assert e.max() <= 2e-5 and (e > 3e-5).mean() == 0.0
+
+
+@pytest.mark.parametrize("scheme,n", [("galaxy", 2048), ("galaxy", 2049), ("random", 2048), ("random", 2049)])
+def test_spelled_out_initial_conditions_match_the_reference_fixtures(O, scheme, n):
+    """The checker of the ON-DEVICE initialisation (oracle.init_*_spelled_out: numpy, every rounding of the compiled
+    reference expressions written out, this host's rand(), glibc's sincosf algorithm restated) against the fixtures
+    made with the compiled reference: bit-identical.  It pins the three things csrc/murb_init.h has to reproduce — the
+    draw order, the float/double mix as the reference's flags compile it, and sincosf."""
+    g = np.load(os.path.join(GOLDEN, f"ref_{scheme}_{n}.npz"))
+    s = (O.init_galaxy_spelled_out if scheme == "galaxy" else O.init_random_spelled_out)(n, 0)
+    for k in ("m", "r", "qx", "qy", "qz", "vx", "vy", "vz"):
+        assert np.array_equal(s[k].view(np.uint32), g["init_" + k][:n].view(np.uint32)), k
+
+
+def test_spelled_out_initial_conditions_benchmark_size(O):
+    g = np.load(os.path.join(GOLDEN, "ref_galaxy_30000_summary.npz"))
+    s = O.init_galaxy_spelled_out(30000, 0)
+    for k in ("m", "r", "qx", "qy", "qz", "vx", "vy", "vz"):
+        a = s[k]
+        got = np.array([a.astype(np.float64).sum(), (a.astype(np.float64) ** 2).sum(), float(np.bitwise_xor.reduce(a.view(np.uint32)))])
+        assert np.array_equal(got, g["init_sum_" + k]), k
+
+
+def test_sincosf_restatement_against_libm(O):
+    """glibc's sincosf algorithm restated (SSE2 build: one rounding per operation) against this host's libm on a dense
+    sweep of the angle range the initial conditions use, (0, 2 pi], plus the tiny and the pi/4 boundaries: identical up to the
+    last bit in a handful of values (the host's libm may run glibc's -mfma build of the same code)."""
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")
+    libm.sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    rng = np.random.default_rng(3)
+    y = np.concatenate([rng.uniform(0, 2 * np.pi, 200000), rng.uniform(0, 2.0 ** -11, 2000), rng.uniform(0.78, 0.79, 2000),
+                        [2.0 ** -12, np.pi / 4, np.pi / 2, np.pi, 2 * np.pi]]).astype(np.float32)
+    s, c = O.sincosf_glibc_sse2(y)
+    sv, cv = C.c_float(), C.c_float()
+    ref = np.empty((len(y), 2), np.float32)
+    for i, v in enumerate(y):
+        libm.sincosf(float(v), C.byref(sv), C.byref(cv))
+        ref[i] = (sv.value, cv.value)
+    ds = np.abs(s.view(np.int32).astype(np.int64) - ref[:, 0].view(np.int32)); dc = np.abs(c.view(np.int32).astype(np.int64) - ref[:, 1].view(np.int32))
+    assert ds.max() <= 1 and dc.max() <= 1
+    assert (ds > 0).sum() + (dc > 0).sum() <= 20, ((ds > 0).sum(), (dc > 0).sum())
