@@ -77,7 +77,7 @@ int murbhip_schedule_items(unsigned long n, int world, int rank, int split, int*
 /* Host only: the same work list as the pair-symmetric kernel consumes it, with the layout of its partial sums —
  * what murbhip_step builds for (n, world, rank) under the given plan (`split` i-side sub-blocks per block, `waves` 4 or 8
  * per workgroup, `taper_pct` % of each launch cut into finer items (+ 256: diagonal blocks as triangular pieces,
- * option "diag_tri"), `tri_first_pct` % of the own-slice triangle in its first launch; exchange_mode != 0 or world > 1: the three-launch pipeline with separate rows for the own-slice
+ * option "diag_tri"; + 512 x k, k = 0..3: the own-slice triangle's launches cut 2^k times finer, option "tri_div"), `tri_first_pct` % of the own-slice triangle in its first launch; exchange_mode != 0 or world > 1: the three-launch pipeline with separate rows for the own-slice
  * triangle).  Per item 8 longs: first i slot, number of i bodies, j block, flags, row set (0 main,
  * 1 own-slice triangle), float offset of its i-side output, of its j-side output, launch (0, 1, 2).
  * flags, exactly as the kernel reads them (MurbSymItem::flags, csrc/murb_kernels_sym.h; SymPiece, csrc/murb_schedule.h):
@@ -232,6 +232,9 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  *                    not walked: the emptier block of a pair goes on the walked (i) side and its items end at its last
  *                    real body; 0 = every block as if full (kept for the A/B: -3 % at N = 30 000, -4 % for a rank of 8
  *                    at N = 200 000)
+ *   "tri_div"        variant 8, several ranks: the items of the own-slice triangle's two launches (which run under the two
+ *                    collectives and, with few blocks per slice, do not fill the chip) cut into 1, 2, 4 or 8 parts more
+ *                    than the rectangles' items; 0 (default) = the plan's choice (~2 rounds of workgroups per launch)
  *   "xcd_order"      variant 8: 0 (default) = j-major item order (round-robin dispatch then gives XCD x the i
  *                    blocks x mod 8 of every j block); 1 = one contiguous run of items per XCD (measured:
  *                    more L2 misses, same time; kept for the comparison)

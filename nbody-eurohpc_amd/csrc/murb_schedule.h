@@ -188,20 +188,26 @@ constexpr int kSymStepBodies = 128;
 //     diagonal block (plain form: the full square, i side kept).
 //   fill: a piece that lies entirely in a block's padding is dropped, one that straddles the end of the real bodies is cut
 //     to the next multiple of `min_len` (sym_orient put the emptier block of a pair on this, the i side).
+//   launch_div (may be empty): every item of launch l is cut into launch_div[l] (a power of two) equal parts at least —
+//     for launches that would otherwise not fill the chip (the own-slice triangle parts of a rank of 8).
 inline void sym_pieces(const std::vector<int>& flat, int split, int taper_pct, int min_len, bool diag_tri, const SymFill& fill,
-                       const std::vector<size_t>& launch_ends, std::vector<SymPiece>& out, std::vector<size_t>& piece_launch_ends)
+                       const std::vector<size_t>& launch_ends, std::vector<SymPiece>& out, std::vector<size_t>& piece_launch_ends,
+                       const std::vector<int>& launch_div = std::vector<int>())
 {
     const int len = MURB_SLICE_ALIGN / split;
     out.clear();
     piece_launch_ends.clear();
     size_t first = 0;
-    for (size_t end : launch_ends) {
+    for (size_t l = 0; l < launch_ends.size(); ++l) {
+        const size_t end = launch_ends[l];
+        const int base_div = l < launch_div.size() ? launch_div[l] : 1;
         const double total = (double)(end - first);
         for (size_t k = first; k < end; ++k) {
             const int isub = flat[2 * k], J = flat[2 * k + 1];
             const bool diag = isub / split == J;
             const double before = (double)(k - first) / (total > 0 ? total : 1.0);
             int div = 1;
+            while (div < base_div && len / (2 * div) >= min_len) div *= 2;
             if (taper_pct > 0) {
                 const double left = 1.0 - before;   // share of the launch still to be dealt, this item included
                 for (double f = taper_pct / 100.0; left <= f && len / (2 * div) >= min_len; f *= 0.5) div *= 2;

@@ -100,6 +100,7 @@ struct Shard {
     int sym_red = 0;                              // i-side reduction of the plan (kernel template parameter)
     long sym_pass_mb = -1;                        // "sym_pass_mb" the passes were cut for
     int sym_pad_aware = -1;                       // ... and "pad_aware"
+    int sym_tri_div = -1;                         // ... and the triangle launches' extra division
     int sym_xcd_order = -1;                       // ... and the item order ("xcd_order")
     int sym_tri_first = -1, sym_overlap = -1;     // ... and the launch boundaries inside the own-slice triangle ("tri_first_pct", "overlap")
     int sym_t1 = 0;                               // items of the triangle's first launch (exchange pipeline, overlap 1)
@@ -173,6 +174,7 @@ struct murbhip_ctx {
     long sym_pass_mb = 0;     // ... one GPU: budget (MiB) for the partial rows of one pass; 0 = a quarter of the device memory
     int sym_red = -1;         // ... i-side reduction in registers (0) or through LDS (1) (-1 = the plan's default)
     int init_libm_fma = -1;   // murbhip_init_bodies: which build of glibc's sincosf to reproduce (-1 = what this host's libm picks)
+    int tri_div = 0;          // ... exchange pipeline: the own-slice triangle's items cut into this many parts more (0 = the plan's choice)
     int pad_aware = 1;        // ... 1: padding slots are not walked (murb_schedule.h, sym_orient); 0: every block as if full (A/B)
     int cu_reserve = 0;       // CUs masked out of the compute streams (left free for the collectives' kernels)
     int solo_shard = -1;      // >= 0: only this shard computes (timing aid: one rank's isolated timeline
@@ -787,7 +789,7 @@ struct SymHostLayout {
 };
 
 void plan_sym_layout(int W, int r, const SymFill& fill, int split, int waves, int taper, bool diag_tri, bool exchange_mode, int overlap,
-                     int tri_first_pct, bool xcd_order, size_t budget_floats, SymHostLayout& L)
+                     int tri_first_pct, bool xcd_order, size_t budget_floats, SymHostLayout& L, int tri_div = 1)
 {
     const int tb = fill.tb;
     std::vector<int> flat;
@@ -801,14 +803,15 @@ void plan_sym_layout(int W, int r, const SymFill& fill, int split, int waves, in
         const size_t n_all = flat.size() / 2;
         t1 = (exchange_mode && overlap == 1) ? (size_t)((long)own * tri_first_pct / 100) : 0;
         std::vector<size_t> launch_ends;
+        std::vector<int> launch_div;   // the own-slice triangle's launches in finer items ("tri_div")
         if (exchange_mode) {
-            if (t1 > 0) launch_ends.push_back(t1);
-            if ((size_t)own > t1) launch_ends.push_back((size_t)own);
-            if (n_all > (size_t)own) launch_ends.push_back(n_all);
+            if (t1 > 0) { launch_ends.push_back(t1); launch_div.push_back(tri_div); }
+            if ((size_t)own > t1) { launch_ends.push_back((size_t)own); launch_div.push_back(tri_div); }
+            if (n_all > (size_t)own) { launch_ends.push_back(n_all); launch_div.push_back(1); }
         } else {
             launch_ends.push_back(n_all);
         }
-        sym_pieces(flat, split, taper, 16 * waves, diag_tri, fill, launch_ends, pieces, piece_ends);
+        sym_pieces(flat, split, taper, 16 * waves, diag_tri, fill, launch_ends, pieces, piece_ends, launch_div);
     };
     build_pieces(xcd_order);
     // Several passes share ONE row buffer and are cut at COLUMN boundaries (cut_passes takes a column to be a contiguous
@@ -850,6 +853,21 @@ void plan_sym_layout(int W, int r, const SymFill& fill, int split, int waves, in
 // unordered body pair is evaluated by exactly one rank.  A rank's partial sums for ALL slices it
 // touched are then row-summed into one chunk per slice and combined with ONE reduce-scatter (each
 // rank receives the complete accelerations of its own bodies); positions travel as before.
+// Exchange pipeline: the own-slice triangle is T_s (T_s + 1) / 2 block pairs in TWO launches (one under each collective); with
+// few blocks per slice neither fills the chip's 4 x CUs workgroup slots and both run at a fraction of the issue rate.
+// Their items (and only theirs) are cut finer until each launch has ~2 rounds of them ("tri_div" overrides).
+int plan_tri_div(const murbhip_ctx* c, const Plan& p)
+{
+    if (c->tri_div > 0) return c->tri_div;
+    if (c->world == 1) return 1;
+    const long tb = (long)(c->slice / MURB_SYM_BLOCK);
+    const long items = tb * (tb + 1) / 2 * p.split / 2;             // per triangle launch
+    const long slots = 4L * std::max(c->cu_count, 1) * 4 / p.waves;  // resident workgroups
+    int div = 1;
+    while (div < 4 && items * div < 2 * slots && MURB_SYM_BLOCK / (p.split * div * 2) >= 16 * p.waves) div *= 2;
+    return div;
+}
+
 // false when the shard's tables were built for exactly this plan and these options.  A rebuild of EXISTING tables needs
 // every shard of the process drained first (the peer-read sums of the previous step may still be reading this shard's
 // send buffer): enqueue_iteration and murbhip_energy do that on the caller's thread before the shards' threads start.
@@ -858,7 +876,7 @@ bool sym_schedule_stale(const murbhip_ctx* c, const Shard& sh, const Plan& p)
     const bool exchange_mode = c->world > 1 || c->force_exchange;
     return !(sh.sym_items && sh.sym_split == p.split && sh.sym_waves == p.waves && sh.sym_taper == p.taper && sh.sym_diag_tri == (int)p.diag_tri &&
              sh.sym_exchange_mode == exchange_mode && sh.sym_xcd_order == c->xcd_order && sh.sym_pass_mb == c->sym_pass_mb &&
-             sh.sym_pad_aware == c->pad_aware &&
+             sh.sym_pad_aware == c->pad_aware && sh.sym_tri_div == plan_tri_div(c, p) &&
              (!exchange_mode || (sh.sym_tri_first == c->tri_first_pct && sh.sym_overlap == c->overlap)));
 }
 
@@ -875,7 +893,7 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
 
     SymHostLayout L;
     plan_sym_layout(c->world, sh.rank, sym_fill(c->n, c->world, c->pad_aware != 0), p.split, p.waves, p.taper, p.diag_tri, exchange_mode,
-                    c->overlap, c->tri_first_pct, c->xcd_order != 0, sym_pass_budget(c) / (3 * sizeof(float)), L);
+                    c->overlap, c->tri_first_pct, c->xcd_order != 0, sym_pass_budget(c) / (3 * sizeof(float)), L, plan_tri_div(c, p));
     if (!exchange_mode && L.passes.size() == 1 && (int)L.table_main.size() != (int)(c->slots / MURB_SYM_BLOCK))
         return MURBHIP_E_STATE;   // the fused row sum + integrate walks every block
     RC_TRY(upload_sym_set(sh, sh.sym_tri, L.table_tri, L.floats_tri));
@@ -883,6 +901,7 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
     sh.sym_main.passes = L.passes;
     sh.sym_pass_mb = c->sym_pass_mb;
     sh.sym_pad_aware = c->pad_aware;
+    sh.sym_tri_div = plan_tri_div(c, p);
     if (L.passes.size() > 1 && !sh.sym_acc64) {
         HIP_TRY(hipMalloc((void**)&sh.sym_acc64, 3 * c->slots * sizeof(double)));
         sh.bytes += 3 * c->slots * sizeof(double);
@@ -1381,12 +1400,12 @@ int murbhip_schedule_layout(unsigned long n, int world, int rank, int split, int
 {
     if (world < 1 || world > MURB_SYM_MAX_RANKS || rank < 0 || rank >= world || !item_count || !row_count) return MURBHIP_E_INVALID;
     if (split != 1 && split != 2 && split != 4 && split != 8 && split != 16) return MURBHIP_E_INVALID;
-    if ((waves != 4 && waves != 8) || taper_pct < 0 || (taper_pct & 0xff) > 100 || taper_pct > 0x1ff || tri_first_pct < 0 || tri_first_pct > 100)
+    if ((waves != 4 && waves != 8) || taper_pct < 0 || (taper_pct & 0xff) > 100 || taper_pct > 0x7ff || tri_first_pct < 0 || tri_first_pct > 100)
         return MURBHIP_E_INVALID;
     if (MURB_SYM_BLOCK / split < 16 * waves) return MURBHIP_E_INVALID;
     SymHostLayout L;
     plan_sym_layout(world, rank, sym_fill(n, world), split, waves, taper_pct & 0xff, (taper_pct & 0x100) != 0,
-                    exchange_mode != 0 || world > 1, 1, tri_first_pct, false, 0, L);
+                    exchange_mode != 0 || world > 1, 1, tri_first_pct, false, 0, L, 1 << ((taper_pct >> 9) & 3));
     *item_count = L.items.size();
     *row_count = L.table_main.size() + L.table_tri.size();
     if (floats_main) *floats_main = L.floats_main;
@@ -1924,6 +1943,7 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     else if (k == "jsplit") { if (value < 0 || value > kMaxParts / 2) return MURBHIP_E_INVALID; c->jsplit = (int)value; }
     else if (k == "xcd_order") c->xcd_order = value ? 1 : 0;
     else if (k == "pad_aware") c->pad_aware = value ? 1 : 0;
+    else if (k == "tri_div") { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return MURBHIP_E_INVALID; c->tri_div = (int)value; }
     else if (k == "init_libm_fma") { if (value < -1 || value > 1) return MURBHIP_E_INVALID; c->init_libm_fma = (int)value; }
     else if (k == "tri_first_pct") { if (value < 0 || value > 100) return MURBHIP_E_INVALID; c->tri_first_pct = (int)value; }
     else if (k == "taper") { if (value < -1 || value > 100) return MURBHIP_E_INVALID; c->taper = (int)value; }

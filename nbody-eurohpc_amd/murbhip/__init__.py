@@ -126,11 +126,12 @@ def schedule_items(n, world, rank, split=1):
     return items, own.value
 
 
-def schedule_layout(n, world, rank, split=1, waves=4, taper=0, tri_first_pct=50, exchange_mode=False, diag_tri=False):
+def schedule_layout(n, world, rank, split=1, waves=4, taper=0, tri_first_pct=50, exchange_mode=False, diag_tri=False, tri_div=1):
     """(items, rows, floats_main, floats_tri): the pair-symmetric work list with its partial-row layout, as arrays of
     8 longs per item and 7 per row-table entry (include/murbhip.h: murbhip_schedule_layout)."""
     ni, nr, fm, ft = C.c_ulong(), C.c_ulong(), C.c_ulong(), C.c_ulong()
-    args = (n, world, rank, split, waves, taper + (256 if diag_tri else 0), tri_first_pct, int(exchange_mode))
+    args = (n, world, rank, split, waves, taper + (256 if diag_tri else 0) + 512 * {1: 0, 2: 1, 4: 2, 8: 3}[tri_div], tri_first_pct,
+            int(exchange_mode))
     _check(lib().murbhip_schedule_layout(*args, None, 0, C.byref(ni), None, 0, C.byref(nr), C.byref(fm), C.byref(ft)),
            "murbhip_schedule_layout")
     items = np.zeros((ni.value, 8), np.int64)

@@ -190,13 +190,14 @@ def test_half_ring_schedule_covers_every_pair_once(mh, n, world, split):
 
 
 @pytest.mark.parametrize("diag_tri", [False, True])
-@pytest.mark.parametrize("n,world,split,waves,taper,exchange", [
+@pytest.mark.parametrize("n,world,split,waves,taper,exchange,tri_div", [p_ if len(p_) == 7 else p_ + (1,) for p_ in [
     (5000, 1, 1, 4, 0, False), (5000, 1, 4, 4, 0, False), (9000, 1, 8, 8, 0, False), (9000, 1, 2, 4, 50, False),
     (9000, 1, 8, 8, 40, False), (9000, 1, 16, 4, 100, False), (3000, 1, 1, 4, 0, True),      # one rank with the exchange pipeline (RCCL self-test)
     (9000, 2, 1, 4, 0, True), (9001, 3, 2, 4, 30, True), (20000, 4, 4, 4, 0, True), (20000, 4, 2, 8, 60, True),
     (30000, 5, 1, 4, 0, True), (60000, 8, 4, 4, 25, True), (30000, 1, 4, 8, 30, False), (2049, 2, 2, 4, 0, True),
-])
-def test_pair_symmetric_layout_is_complete_and_collision_free(mh, n, world, split, waves, taper, exchange, diag_tri):
+    (60000, 8, 4, 4, 0, True, 2), (100000, 8, 4, 4, 0, True, 4), (40000, 4, 2, 8, 20, True, 2),     # the triangle's launches cut finer ("tri_div")
+]])
+def test_pair_symmetric_layout_is_complete_and_collision_free(mh, n, world, split, waves, taper, exchange, diag_tri, tri_div):
     """What the pair-symmetric kernel is handed (murbhip_schedule_layout, host only), for every rank of a run:
       * every ordered (i, j) interaction between REAL bodies is applied exactly once over all items of all ranks (at the
         granularity of 16 slots), with any item size mix the taper produces; nothing is applied twice;
@@ -218,8 +219,10 @@ def test_pair_symmetric_layout_is_complete_and_collision_free(mh, n, world, spli
     recv = np.zeros((world, slice_), np.int64)     # what the reduce-scatter delivers: sum over ranks of their chunk for a slice
     own = np.zeros((world, slice_), np.int64)      # own-triangle row sums (exchange pipeline) / everything (one GPU)
     for r in range(world):
-        items, rows, fm, ft = mh.schedule_layout(n, world, r, split, waves, taper, 50, exchange, diag_tri)
+        items, rows, fm, ft = mh.schedule_layout(n, world, r, split, waves, taper, 50, exchange, diag_tri, tri_div)
         assert len(items) > 0
+        if tri_div > 1:   # the own-slice triangle's items (row set 1) are finer than the rectangles' whole sub-blocks
+            assert items[items[:, 4] == 1][:, 1].max() <= max(1024 // split // tri_div, 16 * waves) and items[items[:, 4] == 0][:, 1].max() == 1024 // split
         sets = {0: np.zeros(fm, np.int32), 1: np.zeros(ft, np.int32)}      # writers per cell
         vals = {0: np.zeros(fm, np.int64), 1: np.zeros(ft, np.int64)}      # real bodies summed into the cell
         needs = {0: np.zeros(fm, bool), 1: np.zeros(ft, bool)}             # cells that belong to a real slot

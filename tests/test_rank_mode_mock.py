@@ -156,7 +156,8 @@ def test_bench_py_with_several_ranks(gpu, world, n):
     if not os.path.exists(MOCK):
         subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "helpers")], check=True, timeout=600)
     env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK, MURB_BENCH_BACKEND="gloo", MURB_BENCH_SHARE_GPU="1",
-               MURB_BENCH_OTHER_CONFIGS="30000:10,60000:5")   # stand-ins for BASELINE's other sizes (the ranks share one GPU here)
+               MURB_BENCH_OTHER_CONFIGS="30000:10,60000:5",   # stand-ins for BASELINE's other sizes (the ranks share one GPU here)
+               MURB_BENCH_UNTIMED_SCALE="0.1")                # ... and every step pays a host-staged collective: fewer untimed steps
     env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)               # bench.py must set it itself in this launch path
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--bodies",
