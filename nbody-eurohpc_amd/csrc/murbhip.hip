@@ -823,7 +823,6 @@ void plan_sym_layout(int W, int r, const SymFill& fill, int split, int waves, in
     // block on its j side: sym_orient puts the emptier block of a pair on the i side)
     size_t own_pieces = pieces.size();
     if (exchange_mode && flat.size() / 2 > (size_t)own) own_pieces = piece_ends.size() >= 2 ? piece_ends[piece_ends.size() - 2] : 0;
-    (void)tb;
     L.items.assign(pieces.size(), MurbSymItem{});
     L.table_main.clear(); L.table_tri.clear();
     L.floats_main = L.floats_tri = 0;
