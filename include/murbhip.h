@@ -255,6 +255,13 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  *                    triangle that is launched before the rectangles, i.e. under the all-gather of positions;
  *                    the rest runs under the reduce-scatter of accelerations.  A tuning knob for real
  *                    interconnect latencies (bench.py picks it per run, untimed)
+ *   "exchange_p2p"   RCCL exchange only (MURBHIP_E_STATE otherwise): 1 = both exchanges of a step as grouped ncclSend / ncclRecv
+ *                    instead of collectives.  Accelerations: under the half-ring schedule a rank only has contributions for
+ *                    the floor(W/2) slices ahead of it, so it sends those chunks straight to their owners and adds up the
+ *                    floor(W/2) it receives (ncclReduceScatter moves and adds zeros for the other half); positions: every
+ *                    slice straight to every peer.  One hop per message on a fully connected xGMI node.  0 (default) =
+ *                    ncclReduceScatter + ncclAllGather.  UNMEASURED on hardware: bench.py times it beside the default for
+ *                    N > 1 ("p2p_plan") so that the first multi-GPU run shows which to prefer
  *   "cu_reserve"     k >= 0 (default 0): the compute streams are re-created with a CU mask that leaves the k highest
  *                    CUs (8 = one per XCD, 16 = two per XCD) to the exchange stream.  The force kernels otherwise fill
  *                    every CU, and a collective's kernel (RCCL) has to wait ~0.1 ms for one of their workgroups to retire

@@ -537,6 +537,18 @@ __global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_integrate
     wa[h] = vx; wa[2 + h] = vy; wb[h] = vz;
 }
 
+// Point-to-point form of the reduce-scatter ("exchange_p2p"): out = this rank's own contribution to its slice + the chunks
+// received from the ranks that evaluated pairs with it, added in the order of their distance along the ring.
+__global__ __launch_bounds__(256) void murb_sym_chunk_sum_kernel(const float* own, const float* received, int nreceived,
+                                                                 unsigned int count, float* out)
+{
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    float acc = own[k];
+    for (int d = 0; d < nreceived; ++d) acc += received[(unsigned long)d * count + k];
+    out[k] = acc;
+}
+
 // Reduce-scatter by peer reads (one process, several shards): out = sum over shards of their chunk.
 struct MurbPeerPtrs {
     const float* p[MURB_SYM_MAX_RANKS];

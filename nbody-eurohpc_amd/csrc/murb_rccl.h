@@ -25,6 +25,8 @@ struct Rccl {
     int (*ReduceScatter)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;   // point-to-point form of the exchange
+    int (*Recv)(void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;         // ("exchange_p2p"), optional
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
 };
@@ -56,8 +58,11 @@ Rccl& rccl()
         (int (*)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(r.lib, "ncclReduceScatter");
     r.GroupStart = (int (*)())dlsym(r.lib, "ncclGroupStart");
     r.GroupEnd = (int (*)())dlsym(r.lib, "ncclGroupEnd");
+    r.Send = (int (*)(const void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(r.lib, "ncclSend");
+    r.Recv = (int (*)(void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(r.lib, "ncclRecv");
     r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
-    // ncclGroupStart/End are bound but not needed: every communicator is driven by a thread of its own (ShardCrew)
+    // ncclGroupStart/End are not needed for the collectives: every communicator is driven by a thread of its own (ShardCrew);
+    // only the optional point-to-point exchange groups its sends and receives
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllGather && r.ReduceScatter;
     return r;
 }

@@ -109,6 +109,7 @@ struct Shard {
     SymSet sym_tri;              // exchange pipeline: the own-slice triangle (never enters the reduce-scatter)
     float* sym_send = nullptr;   // [world][3][slice]
     float* sym_recv = nullptr;   // [3][slice]
+    float* sym_p2p = nullptr;    // "exchange_p2p": chunks received from the floor(W/2) ranks behind this one [floor(W/2)][3][slice]
     float* sym_tri_acc = nullptr;// row sums of sym_tri [3][slice]
     double* sym_acc64 = nullptr; // multi-pass evaluation: fp64 row sums accumulated over the passes [3][slots]
     size_t sym_bytes = 0;        // device bytes of all of the above
@@ -174,6 +175,7 @@ struct murbhip_ctx {
     long sym_pass_mb = 0;     // ... one GPU: budget (MiB) for the partial rows of one pass; 0 = a quarter of the device memory
     int sym_red = -1;         // ... i-side reduction in registers (0) or through LDS (1) (-1 = the plan's default)
     int init_libm_fma = -1;   // murbhip_init_bodies: which build of glibc's sincosf to reproduce (-1 = what this host's libm picks)
+    int exchange_p2p = 0;     // RCCL exchange by grouped ncclSend/ncclRecv instead of ncclReduceScatter / ncclAllGather
     int tri_div = 0;          // ... exchange pipeline: the own-slice triangle's items cut into this many parts more (0 = the plan's choice)
     int pad_aware = 1;        // ... 1: padding slots are not walked (murb_schedule.h, sym_orient); 0: every block as if full (A/B)
     int cu_reserve = 0;       // CUs masked out of the compute streams (left free for the collectives' kernels)
@@ -654,6 +656,16 @@ int shard_exchange(murbhip_ctx* c, Shard& sh, int buf, int failed)
         span = span_begin(c, sh, kProfAllGather, sh.comm, &rc);
         RC_TRY(rc);
         float4* base = sh.rec[buf];
+        if (c->exchange_p2p && c->world > 1) {   // every slice straight to every peer: W - 1 sends and receives, one hop each
+            Rccl& r = rccl();
+            RC_TRY(nccl_rc(r.GroupStart()));
+            for (int d = 1; d < c->world; ++d) {
+                const int to = (sh.rank + d) % c->world, from = (sh.rank - d + c->world) % c->world;
+                RC_TRY(nccl_rc(r.Send(base + (size_t)sh.rank * slice_f4, slice_f4 * 4, kRcclFloat, to, sh.comm_rccl, sh.comm)));
+                RC_TRY(nccl_rc(r.Recv(base + (size_t)from * slice_f4, slice_f4 * 4, kRcclFloat, from, sh.comm_rccl, sh.comm)));
+            }
+            RC_TRY(nccl_rc(r.GroupEnd()));
+        } else
         RC_TRY(nccl_rc(rccl().AllGather(base + (size_t)sh.rank * slice_f4, base, slice_f4 * 4, kRcclFloat, sh.comm_rccl, sh.comm)));
     } else {
         if (idle) return 0;
@@ -928,6 +940,11 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
             HIP_TRY(hipMalloc((void**)&sh.sym_send, chunk * W));
             HIP_TRY(hipMalloc((void**)&sh.sym_recv, chunk));
             HIP_TRY(hipMalloc((void**)&sh.sym_tri_acc, chunk));
+            if (W > 1) {   // receive area of the point-to-point exchange (read as 0 where nothing has arrived yet)
+                HIP_TRY(hipMalloc((void**)&sh.sym_p2p, chunk * (size_t)(W / 2)));
+                HIP_TRY(hipMemsetAsync(sh.sym_p2p, 0, chunk * (size_t)(W / 2), sh.compute));
+                sh.bytes += chunk * (size_t)(W / 2);
+            }
             HIP_TRY(hipEventCreateWithFlags(&sh.ev_rowsum, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&sh.ev_reduced, hipEventDisableTiming));
             sh.bytes += chunk * (W + 2);
@@ -988,7 +1005,26 @@ int shard_reduce_scatter(murbhip_ctx* c, Shard& sh)
     const unsigned int chunk_floats = (unsigned int)(3 * c->slice);
     const bool idle = is_idle(c, sh);
     int rc = 0, span = -1;
-    if (c->exchange == 1) {
+    if (c->exchange == 1 && c->exchange_p2p && c->world > 1) {
+        // Point-to-point form.  Under the half-ring schedule a rank only has contributions for the floor(W/2) slices ahead of
+        // it (and its own): the reduce-scatter moves and adds zeros for the rest.  Here every rank sends those chunks straight
+        // to their owners (one xGMI hop each, all links at once) and adds up what the floor(W/2) ranks behind it sent.
+        Rccl& r = rccl();
+        const int W = c->world, D = W / 2;
+        HIP_TRY(hipStreamWaitEvent(sh.comm, sh.ev_rowsum, 0));
+        span = span_begin(c, sh, kProfReduceScatter, sh.comm, &rc);
+        RC_TRY(rc);
+        RC_TRY(nccl_rc(r.GroupStart()));
+        for (int d = 1; d <= D; ++d) {
+            const int to = (sh.rank + d) % W, from = (sh.rank - d + W) % W;
+            RC_TRY(nccl_rc(r.Send(sh.sym_send + (size_t)to * chunk_floats, chunk_floats, kRcclFloat, to, sh.comm_rccl, sh.comm)));
+            RC_TRY(nccl_rc(r.Recv(sh.sym_p2p + (size_t)(d - 1) * chunk_floats, chunk_floats, kRcclFloat, from, sh.comm_rccl, sh.comm)));
+        }
+        RC_TRY(nccl_rc(r.GroupEnd()));
+        hipLaunchKernelGGL(murb_sym_chunk_sum_kernel, dim3((chunk_floats + 255) / 256), dim3(256), 0, sh.comm,
+                           sh.sym_send + (size_t)sh.rank * chunk_floats, sh.sym_p2p, D, chunk_floats, sh.sym_recv);
+        RC_TRY(hip_rc(hipGetLastError()));
+    } else if (c->exchange == 1) {
         HIP_TRY(hipStreamWaitEvent(sh.comm, sh.ev_rowsum, 0));
         span = span_begin(c, sh, kProfReduceScatter, sh.comm, &rc);
         RC_TRY(rc);
@@ -1514,7 +1550,7 @@ int murbhip_destroy(murbhip_ctx* c)
         if (sh.comm) hipStreamDestroy(sh.comm);
         hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out); hipFree(sh.phi_out); hipFree(sh.mass); hipFree(sh.radius); hipFree(sh.metrics);
         hipFree(sh.sym_items); free_sym_set(sh.sym_main); free_sym_set(sh.sym_tri);
-        hipFree(sh.sym_send); hipFree(sh.sym_recv); hipFree(sh.sym_tri_acc); hipFree(sh.sym_acc64);
+        hipFree(sh.sym_send); hipFree(sh.sym_recv); hipFree(sh.sym_p2p); hipFree(sh.sym_tri_acc); hipFree(sh.sym_acc64);
         if (sh.ev_rowsum) hipEventDestroy(sh.ev_rowsum);
         if (sh.ev_reduced) hipEventDestroy(sh.ev_reduced);
     }
@@ -1942,6 +1978,11 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     else if (k == "jsplit") { if (value < 0 || value > kMaxParts / 2) return MURBHIP_E_INVALID; c->jsplit = (int)value; }
     else if (k == "xcd_order") c->xcd_order = value ? 1 : 0;
     else if (k == "pad_aware") c->pad_aware = value ? 1 : 0;
+    else if (k == "exchange_p2p") {
+        if (value && (c->exchange != 1 || !rccl().Send || !rccl().Recv)) return MURBHIP_E_STATE;   // needs the RCCL exchange and ncclSend/ncclRecv
+        RC_TRY(murbhip_sync(c));
+        c->exchange_p2p = value ? 1 : 0;
+    }
     else if (k == "tri_div") { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return MURBHIP_E_INVALID; c->tri_div = (int)value; }
     else if (k == "init_libm_fma") { if (value < -1 || value > 1) return MURBHIP_E_INVALID; c->init_libm_fma = (int)value; }
     else if (k == "tri_first_pct") { if (value < 0 || value > 100) return MURBHIP_E_INVALID; c->tri_first_pct = (int)value; }

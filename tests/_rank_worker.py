@@ -20,6 +20,9 @@ with murbhip.Simulation(n, soft=2e8, device=0, rank=rank, world=world, uid=uid) 
     sim.set_option("overlap", overlap)
     sim.set_option("jsplit", jsplit)
     sim.set_option("integrator", integrator)
+    for kv in filter(None, os.environ.get("MURB_TEST_OPTIONS", "").split(",")):   # further library options: "key=value,key=value"
+        key, value = kv.split("=")
+        sim.set_option(key, int(value))
     sim.upload(s)
     sim.compute_acc()
     sim.sync()

@@ -17,6 +17,9 @@ s = murbhip.init_bodies(n, "galaxy")
 with murbhip.Simulation(n, soft=2e8) as one, murbhip.Simulation(n, soft=2e8, devices=[0] * shards, exchange="rccl") as many:
     many.set_option("variant", variant)
     many.set_option("overlap", overlap)
+    for kv in filter(None, os.environ.get("MURB_TEST_OPTIONS", "").split(",")):   # further library options: "key=value,key=value"
+        key, value = kv.split("=")
+        many.set_option(key, int(value))
     for sim in (one, many):
         sim.upload(s)
         sim.steps(3600.0, 4)

@@ -17,6 +17,8 @@
 //                    what it gives is the step time of one real rank process (its own three streams) without the wire.
 //   sync             each call drains its stream, stages through host memory and returns when the result
 //                    is in place (the behaviour of round 1).
+// Point-to-point: ncclSend / ncclRecv inside ncclGroupStart / ncclGroupEnd (the library's "exchange_p2p"), between processes
+// through the shared segment and between the shard threads of one process through the staging ring; same modes.
 // Loaded only when MURBHIP_RCCL_LIBRARY points at it (tests/test_rank_mode_mock.py).
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
@@ -67,6 +69,11 @@ struct LocalGroup {
     std::vector<unsigned long> calls; // per rank: collectives issued so far (picks the staging buffer)
     std::atomic<int> failed{0};
 };
+// point-to-point operations collect between ncclGroupStart and ncclGroupEnd (per calling thread: in the one-process mode every
+// communicator has a thread of its own) and run at the end of the group
+struct P2POp { bool send; void* buf; size_t count; int peer; Comm* comm; hipStream_t stream; };
+thread_local std::vector<P2POp> p2p_pending;
+thread_local int group_depth = 0;
 struct Id { char bytes[128]; };
 std::string segment_name(const Id& id)
 {
@@ -184,6 +191,81 @@ int run_local(Comm* c, int kind, const void* send, void* recv, size_t count, hip
     if (hipMemcpyAsync(recv, src, floats * 4, hipMemcpyHostToDevice, stream) != hipSuccess ||
         hipEventRecord(st.done[(size_t)r], stream) != hipSuccess)
         return kSystem;
+    if (sync && hipStreamSynchronize(stream) != hipSuccess) return kSystem;
+    st.used.store(true);
+    return kOk;
+}
+
+// One group of sends and receives of one rank (all of `count` floats, all on one stream).  Staging slot [src][dst].  Like the
+// collectives above: asynchronous towards the GPU, every rank (thread) of the communicator must issue its group, and they meet
+// inside (a real library only pairs senders with receivers; the library under test issues the same groups on every rank).
+int run_p2p(std::vector<P2POp>& ops)
+{
+    if (ops.empty()) return kOk;
+    Comm* c = ops[0].comm;
+    hipStream_t stream = ops[0].stream;
+    const size_t count = ops[0].count, n = (size_t)c->nranks;
+    for (const P2POp& op : ops)
+        if (op.comm != c || op.stream != stream || op.count != count || op.peer < 0 || op.peer >= c->nranks || op.peer == c->rank) return kInvalid;
+    const size_t need = n * n * count;
+    if (solo_mode()) return kOk;   // nobody to talk to: receive buffers keep what they hold
+    const bool sync = !async_mode();
+    const int r = c->rank;
+    if (!c->local) {               // ranks are processes: through the shared segment
+        if (need * 4 > kCapacity) return kInvalid;
+        float* stage = reinterpret_cast<float*>(c->seg->data);
+        if (sync && hipStreamSynchronize(stream) != hipSuccess) return kSystem;
+        for (const P2POp& op : ops)
+            if (op.send && hipMemcpyAsync(stage + ((size_t)r * n + (size_t)op.peer) * count, op.buf, count * 4, hipMemcpyDeviceToHost, stream) != hipSuccess)
+                return kSystem;
+        if (sync) { if (hipStreamSynchronize(stream) != hipSuccess) return kSystem; pthread_barrier_wait(&c->seg->barrier); }
+        else if (hipLaunchHostFunc(stream, host_barrier, c) != hipSuccess) return kSystem;
+        for (const P2POp& op : ops)
+            if (!op.send && hipMemcpyAsync(op.buf, stage + ((size_t)op.peer * n + (size_t)r) * count, count * 4, hipMemcpyHostToDevice, stream) != hipSuccess)
+                return kSystem;
+        if (sync) { if (hipStreamSynchronize(stream) != hipSuccess) return kSystem; pthread_barrier_wait(&c->seg->barrier); }
+        else if (hipLaunchHostFunc(stream, host_barrier, c) != hipSuccess) return kSystem;
+        return kOk;
+    }
+    // ranks are threads of this process: the staging ring of run_local
+    LocalGroup* g = c->local;
+    Staging& st = g->ring[g->calls[(size_t)r]++ % 4];
+    int rc = kOk;
+    if (st.used.load())
+        for (hipEvent_t e : st.done)
+            if (hipEventSynchronize(e) != hipSuccess) rc = kSystem;
+    if (st.floats < need || st.copied.empty()) {
+        pthread_barrier_wait(&g->barrier);
+        if (r == 0) {
+            if (st.floats < need) {
+                if (st.host) (void)hipHostFree(st.host);
+                if (hipHostMalloc((void**)&st.host, need * 4, hipHostMallocDefault) != hipSuccess) { g->failed.store(1); st.host = nullptr; }
+                st.floats = st.host ? need : 0;
+            }
+            if (st.copied.empty()) {
+                st.copied.resize(n); st.done.resize(n);
+                for (size_t k = 0; k < n; ++k)
+                    if (hipEventCreateWithFlags(&st.copied[k], hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&st.done[k], hipEventDisableTiming) != hipSuccess) g->failed.store(1);
+            }
+        }
+        pthread_barrier_wait(&g->barrier);
+    }
+    if (g->failed.load()) rc = kSystem;
+    for (const P2POp& op : ops)
+        if (rc == kOk && op.send &&
+            hipMemcpyAsync(st.host + ((size_t)r * n + (size_t)op.peer) * count, op.buf, count * 4, hipMemcpyDeviceToHost, stream) != hipSuccess)
+            rc = kSystem;
+    if (rc == kOk && hipEventRecord(st.copied[(size_t)r], stream) != hipSuccess) rc = kSystem;
+    if (rc == kOk && sync && hipStreamSynchronize(stream) != hipSuccess) rc = kSystem;
+    if (rc != kOk) g->failed.store(1);
+    pthread_barrier_wait(&g->barrier);   // every rank's sends are enqueued and their `copied` events recorded
+    if (g->failed.load()) return kSystem;
+    for (const P2POp& op : ops)
+        if (!op.send && (hipStreamWaitEvent(stream, st.copied[(size_t)op.peer], 0) != hipSuccess ||
+                         hipMemcpyAsync(op.buf, st.host + ((size_t)op.peer * n + (size_t)r) * count, count * 4, hipMemcpyHostToDevice, stream) != hipSuccess))
+            return kSystem;
+    if (hipEventRecord(st.done[(size_t)r], stream) != hipSuccess) return kSystem;
     if (sync && hipStreamSynchronize(stream) != hipSuccess) return kSystem;
     st.used.store(true);
     return kOk;
@@ -349,8 +431,27 @@ int ncclReduceScatter(const void* send, void* recv, size_t recvcount, int dtype,
     return kOk;
 }
 
-int ncclGroupStart() { return kOk; }   // the library issues no grouped calls any more; kept for the binding
-int ncclGroupEnd() { return kOk; }
+// groups only matter for the point-to-point calls (the library issues its collectives ungrouped, one thread per communicator)
+int ncclGroupStart() { ++group_depth; return kOk; }
+int ncclGroupEnd()
+{
+    if (group_depth <= 0 || --group_depth > 0) return kOk;
+    const int rc = run_p2p(p2p_pending);
+    p2p_pending.clear();
+    return rc;
+}
+int ncclSend(const void* send, size_t count, int dtype, int peer, void* comm, hipStream_t stream)
+{
+    if (!comm || dtype != 7 || group_depth == 0) return kInvalid;   // the library always groups its sends and receives
+    p2p_pending.push_back(P2POp{true, const_cast<void*>(send), count, peer, static_cast<Comm*>(comm), stream});
+    return kOk;
+}
+int ncclRecv(void* recv, size_t count, int dtype, int peer, void* comm, hipStream_t stream)
+{
+    if (!comm || dtype != 7 || group_depth == 0) return kInvalid;
+    p2p_pending.push_back(P2POp{false, recv, count, peer, static_cast<Comm*>(comm), stream});
+    return kOk;
+}
 const char* ncclGetErrorString(int code) { return code == kOk ? "no error" : code == kInvalid ? "mock: invalid argument" : "mock: system error"; }
 
 }  // extern "C"

@@ -22,12 +22,12 @@ WORKER = os.path.join(ROOT, "tests", "_rank_worker.py")
 SOFT, DT = np.float32(2e8), np.float32(3600.0)
 
 
-def run_ranks(tmp_path, world, n, steps, variant, overlap=1, jsplit=0, integrator=0, mode="async"):
+def run_ranks(tmp_path, world, n, steps, variant, overlap=1, jsplit=0, integrator=0, mode="async", options=""):
     """mode: "async" = the stand-in only enqueues its copies and host functions on the stream it is given (what real
     RCCL does; a missing cross-stream wait in the library then shows as a wrong result), "sync" = it drains the stream."""
     if not os.path.exists(MOCK):   # normally built by __graft_entry__.build()
         subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "helpers")], check=True, timeout=600)
-    env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK, MURB_MOCK_MODE=mode)
+    env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK, MURB_MOCK_MODE=mode, MURB_TEST_OPTIONS=options)
     # the unique id comes from the same library the ranks will bind: ask a throw-away process for it
     uid = subprocess.run([sys.executable, "-c",
                           f"import sys; sys.path.insert(0, {os.path.join(ROOT, 'nbody-eurohpc_amd')!r}); import murbhip; "
@@ -69,10 +69,14 @@ def run_ranks(tmp_path, world, n, steps, variant, overlap=1, jsplit=0, integrato
     (2, 9000, 8, 1, 0, "sync"),       # the draining stand-in of round 1, for comparison
     (4, 20000, 8, 1, 4, "sync"),
     (4, 30000, 0, 1, 0, "async"),     # BASELINE's N = 30 000 on 4 ranks with the plan the library picks itself (variant 0)
+    # the point-to-point form of both exchanges ("exchange_p2p": grouped ncclSend / ncclRecv instead of the collectives)
+    (2, 9000, 8, 1, 0, "async+p2p"), (3, 9001, 8, 1, 2, "async+p2p"), (4, 20000, 8, 1, 4, "async+p2p"), (4, 40000, 8, 2, 0, "async+p2p"),
+    (3, 10003, 1, 1, 0, "async+p2p"), (4, 20000, 8, 0, 0, "sync+p2p"),
 ])
 def test_ranks_match_single_gpu(gpu, O, tmp_path, world, n, variant, overlap, jsplit, mode):
     steps = 3 if n < 40000 else 6
-    ranks = run_ranks(tmp_path, world, n, steps, variant, overlap, jsplit, mode=mode)
+    mode, _, p2p = mode.partition("+")
+    ranks = run_ranks(tmp_path, world, n, steps, variant, overlap, jsplit, mode=mode, options="exchange_p2p=1" if p2p else "")
     s = O.init_bodies(n, "galaxy")
     with gpu.Simulation(n, soft=SOFT) as one:
         one.upload(s)
@@ -106,14 +110,14 @@ def test_ranks_match_single_gpu(gpu, O, tmp_path, world, n, variant, overlap, js
     assert abs(sum(float(d["pe"]) for d in ranks) - pe) <= 1e-5 * abs(pe)
 
 
-@pytest.mark.parametrize("world,n,overlap", [(4, 20000, 1), (3, 15000, 2)])
-def test_long_rank_mode_run_with_asynchronous_collectives(gpu, O, tmp_path, world, n, overlap):
+@pytest.mark.parametrize("world,n,overlap,options", [(4, 20000, 1, ""), (3, 15000, 2, ""), (4, 20000, 1, "exchange_p2p=1")])
+def test_long_rank_mode_run_with_asynchronous_collectives(gpu, O, tmp_path, world, n, overlap, options):
     """300 steps, every one with a reduce-scatter and an all-gather that only ENQUEUE work on the library's exchange stream
     (the stand-in's async mode): a missing dependency between the compute and exchange streams — reading positions before
     they are gathered, overwriting the send buffer before it is reduced, integrating before the sums arrive — has 600
     chances to show as a divergence from the single-GPU trajectory.  All ranks must end with bit-identical positions."""
     steps = 300
-    ranks = run_ranks(tmp_path, world, n, steps, 8, overlap=overlap, mode="async")
+    ranks = run_ranks(tmp_path, world, n, steps, 8, overlap=overlap, mode="async", options=options)
     s = O.init_bodies(n, "galaxy")
     with gpu.Simulation(n, soft=SOFT) as one:
         one.upload(s)
@@ -188,6 +192,8 @@ def test_bench_py_with_several_ranks(gpu, world, n):
     assert ex["payload_bytes_per_rank"]["all_gather_out"] == world * ex["payload_bytes_per_rank"]["all_gather_in"]
     alt = d["one_sided_plan"]
     assert alt["ms_per_step"] > 0 and abs(alt["half_ring_speedup"] - alt["ms_per_step"] / d["ms_per_step"]) < 1e-9
+    p2p = d["p2p_plan"]                # both exchanges as grouped sends / receives, timed beside the collectives
+    assert p2p["ms_per_step"] > 0 and abs(p2p["speedup_over_collectives"] - p2p["collectives_ms_per_step_same_context"] / p2p["ms_per_step"]) < 1e-9
     oc = {e["n_bodies"]: e for e in d["other_configs"]}
     assert set(oc) == {30000, 60000}
     for e in oc.values():
@@ -253,8 +259,10 @@ def test_bench_py_reports_a_failed_start(gpu):
     assert d["value"] is None and "librccl could not be loaded" in d["error"] and d["phase"] == "context + upload"
 
 
-@pytest.mark.parametrize("shards,n,variant,overlap", [(2, 9000, 8, 1), (3, 9001, 8, 0), (4, 20000, 8, 1), (3, 9000, 1, 1)])
-def test_one_process_several_shards_over_rccl_calls(gpu, shards, n, variant, overlap):
+@pytest.mark.parametrize("shards,n,variant,overlap,options", [(2, 9000, 8, 1, ""), (3, 9001, 8, 0, ""), (4, 20000, 8, 1, ""), (3, 9000, 1, 1, ""),
+                                                              (4, 20000, 8, 1, "exchange_p2p=1"), (5, 30000, 8, 1, "exchange_p2p=1"),
+                                                              (3, 9000, 1, 1, "exchange_p2p=1")])
+def test_one_process_several_shards_over_rccl_calls(gpu, shards, n, variant, overlap, options):
     """`--im hip+tile+multi` on a multi-GPU node = murbhip_create_sharded(..., exchange = RCCL): ncclCommInitAll, then
     every shard's own host thread (the library's ShardCrew) issues that shard's all-gather and reduce-scatter on its own
     communicator — no ncclGroupStart/End.  With all shards on GPU 0 the calls go to the stand-in library, whose local mode
@@ -262,7 +270,7 @@ def test_one_process_several_shards_over_rccl_calls(gpu, shards, n, variant, ove
     callers' streams (asynchronous towards the GPU, like RCCL)."""
     if not os.path.exists(MOCK):
         subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "helpers")], check=True, timeout=600)
-    env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK)
+    env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK, MURB_TEST_OPTIONS=options)   # "exchange_p2p=1": grouped sends / receives per shard thread
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_sharded_rccl_worker.py"), str(shards), str(n), str(variant),
                         str(overlap)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
