@@ -39,6 +39,7 @@
 #include <vector>
 
 #include "../../include/murbhip.h"
+#include "murb_crew.h"
 #include "murb_init.h"
 #include "murb_kernels_sym.h"
 #include "murb_rccl.h"
@@ -139,8 +140,6 @@ enum ProfKind {
     kProfStep,            // compute stream: first launch of a step to the end of its state update
     kProfKinds
 };
-
-class ShardCrew;
 
 }  // namespace
 
@@ -397,111 +396,17 @@ Plan make_plan(const murbhip_ctx* c)
     return p;
 }
 
-// ---- the shards' host threads ------------------------------------------------------------------------------------------
-// The reference drives its simulation from ONE host thread (main.cpp:348-354) and so does every caller of this library.
-// A context with several shards nevertheless enqueues a step from one thread PER SHARD: each shard's share of a step is
-// ~25 HIP calls (5 launches, 2 collectives or W peer copies, the events between them), measured at 100-140 us per shard
-// and step when one thread issues them for 8 shards in turn — 0.8-1.1 ms of host time per step against 0.9 ms of GPU
-// work per rank at N = 200 000 (profiles/r03_host_enqueue.txt), and the collectives cannot complete before the LAST
-// shard's call has been issued.  run() hands every thread the same job and returns when all have finished enqueueing
-// (never waits for the GPU); meet() is a barrier among the threads, needed only where a shard's stream has to wait for an
-// event another shard's thread records (peer-copy exchange).  With one shard there is no thread: the caller runs the job.
-class ShardCrew {
-public:
-    explicit ShardCrew(murbhip_ctx* c) : c_(c), n_((int)c->shards.size())
-    {
-        if (n_ < 2) return;
-        rc_.assign((size_t)n_, 0);
-        for (int i = 0; i < n_; ++i) threads_.emplace_back([this, i] { work(i); });
-    }
-    ~ShardCrew()
-    {
-        if (threads_.empty()) return;
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++generation_; }
-        cv_work_.notify_all();
-        for (std::thread& t : threads_) t.join();
-    }
-    ShardCrew(const ShardCrew&) = delete;
-    ShardCrew& operator=(const ShardCrew&) = delete;
-
-    // job(shard) on every shard's thread; first failure (in shard order) or 0
-    int run(const std::function<int(Shard&)>& job)
-    {
-        if (threads_.empty()) {
-            Shard& sh = c_->shards[0];
-            const int rc = hip_rc(hipSetDevice(sh.device));
-            return rc ? rc : job(sh);
-        }
-        job_ = &job;
-        remaining_.store(n_, std::memory_order_relaxed);
-        { std::lock_guard<std::mutex> lk(m_); ++generation_; }
-        cv_work_.notify_all();
-        for (int spins = 0; remaining_.load(std::memory_order_acquire) != 0;) {   // enqueueing takes ~100 us: spin first
-            if (++spins < 20000) relax();
-            else {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_done_.wait(lk, [this] { return remaining_.load(std::memory_order_acquire) == 0; });
-            }
-        }
-        job_ = nullptr;
-        for (int rc : rc_) if (rc != 0) return rc;
-        return 0;
-    }
-
-    // barrier among the shard threads (call it from inside a job, from EVERY shard's job, failed or not)
-    void meet()
-    {
-        if (threads_.empty()) return;
-        const unsigned my = phase_.load(std::memory_order_acquire);
-        if (arrived_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) {
-            arrived_.store(0, std::memory_order_relaxed);
-            phase_.fetch_add(1, std::memory_order_release);
-            return;
-        }
-        for (int spins = 0; phase_.load(std::memory_order_acquire) == my;) {
-            if (++spins < 4000) relax(); else std::this_thread::yield();
-        }
-    }
-
-private:
-    static void relax() { __builtin_ia32_pause(); }
-    void work(int i)
-    {
-        Shard& sh = c_->shards[(size_t)i];
-        (void)hipSetDevice(sh.device);   // for the life of the thread: no hipSetDevice on the per-step path
-        unsigned long seen = 0;
-        for (;;) {
-            {   // the next job usually follows within microseconds (murbhip_steps): spin briefly, then sleep
-                int spins = 0;
-                while (generation_.load(std::memory_order_acquire) == seen && ++spins < 4000) relax();
-                if (generation_.load(std::memory_order_acquire) == seen) {
-                    std::unique_lock<std::mutex> lk(m_);
-                    cv_work_.wait(lk, [&] { return generation_.load(std::memory_order_acquire) != seen; });
-                }
-            }
-            seen = generation_.load(std::memory_order_acquire);
-            if (stop_) return;
-            rc_[(size_t)i] = (*job_)(sh);
-            if (remaining_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-                std::lock_guard<std::mutex> lk(m_);
-                cv_done_.notify_one();
-            }
-        }
-    }
-
-    murbhip_ctx* c_;
-    int n_;
-    std::vector<std::thread> threads_;
-    std::vector<int> rc_;
-    const std::function<int(Shard&)>* job_ = nullptr;
-    std::mutex m_;
-    std::condition_variable cv_work_, cv_done_;
-    std::atomic<unsigned long> generation_{0};
-    std::atomic<int> remaining_{0};
-    std::atomic<int> arrived_{0};
-    std::atomic<unsigned> phase_{0};
-    bool stop_ = false;
-};
+// ---- the shards' host threads: ShardCrew (murb_crew.h), one member per shard, bound to its device for life ---------------
+// run() hands every member the same job for ITS shard and returns when all have finished enqueueing (never waits for the GPU);
+// with one shard there is no thread: the caller runs the job.
+int crew_run(murbhip_ctx* c, const std::function<int(Shard&)>& job)
+{
+    return c->crew->run([&](int i) -> int {
+        Shard& sh = c->shards[(size_t)i];
+        if (c->crew->threads() == 0) RC_TRY(hip_rc(hipSetDevice(sh.device)));   // a member thread set its device when it started
+        return job(sh);
+    });
+}
 
 // ---- timing spans ("profile") --------------------------------------------------------------------------------------------
 // A span = two events recorded on `stream` around something; -1 = not recording (profiling off, level too low, pool empty:
@@ -1231,9 +1136,9 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
         if (stale) RC_TRY(murbhip_sync(c));   // tables are rebuilt below: nothing may be in flight
     }
     if (p.symmetric && exchanging)
-        RC_TRY(c->crew->run([&](Shard& sh) { return shard_iteration_sym_multi(c, sh, p, dt, update_state); }));
+        RC_TRY(crew_run(c, [&](Shard& sh) { return shard_iteration_sym_multi(c, sh, p, dt, update_state); }));
     else
-        RC_TRY(c->crew->run([&](Shard& sh) { return shard_iteration_plain(c, sh, p, dt, update_state, reuse); }));
+        RC_TRY(crew_run(c, [&](Shard& sh) { return shard_iteration_plain(c, sh, p, dt, update_state, reuse); }));
     if (p.symmetric && exchanging) c->reduce_pending = true;
     if (update_state) {
         if (exchanging) c->gather_pending = true;
@@ -1335,7 +1240,11 @@ int create_common(murbhip_ctx** out, unsigned long n, float soft, float g, int w
                 }
     }
     if (rc != 0) { murbhip_destroy(c); return rc; }
-    c->crew = new (std::nothrow) ShardCrew(c);   // after the shards exist: its threads bind to their devices at once
+    {   // after the shards exist: the members bind to their devices at once
+        std::vector<int> devs;
+        for (const Shard& sh : c->shards) devs.push_back(sh.device);
+        c->crew = new (std::nothrow) ShardCrew((int)devs.size(), [devs](int i) { (void)hipSetDevice(devs[(size_t)i]); });
+    }
     if (!c->crew) { murbhip_destroy(c); return MURBHIP_E_NOMEM; }
     *out = c;
     return 0;
@@ -1833,7 +1742,7 @@ int murbhip_integrate_host_acc(murbhip_ctx* c, const float* ax, const float* ay,
         RC_TRY(enqueue_integrate(c, sh, 1, dt, 1, nullptr, 0));
     }
     if (c->world > 1) {
-        RC_TRY(c->crew->run([&](Shard& sh) { return shard_exchange(c, sh, c->cur ^ 1, 0); }));
+        RC_TRY(crew_run(c, [&](Shard& sh) { return shard_exchange(c, sh, c->cur ^ 1, 0); }));
         c->gather_pending = true;
     }
     c->cur ^= 1;
@@ -1923,7 +1832,7 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
         if (stale) RC_TRY(murbhip_sync(c));
     }
     if (symmetric_multi) {
-        RC_TRY(c->crew->run([&](Shard& sh) { return shard_potential_sym_multi(c, sh, main_plan); }));
+        RC_TRY(crew_run(c, [&](Shard& sh) { return shard_potential_sym_multi(c, sh, main_plan); }));
         c->reduce_pending = true;
     }
     for (Shard& sh : c->shards) {

@@ -289,6 +289,20 @@ def test_pair_symmetric_layout_is_complete_and_collision_free(mh, n, world, spli
     assert ((own + recv).reshape(-1)[real] == n).all()
 
 
+@pytest.mark.parametrize("binary,members,rounds", [("crew_selftest", 8, 2000), ("crew_selftest", 1, 50), ("crew_selftest", 3, 2000),
+                                                   ("crew_selftest_tsan", 6, 300)])
+def test_shard_crew_selftest(binary, members, rounds):
+    """The per-shard host threads of the library (csrc/murb_crew.h: run / meet, no HIP in it) driven on the CPU: every member
+    runs every job once on its own thread, meet() and run() are barriers (members of different speed), a failing member's
+    code comes back while the barriers still pair up, sleeping members wake up, destruction joins them.  Once more under
+    ThreadSanitizer (host code only): no data race in the hand-over of jobs and results."""
+    exe = os.path.join(ROOT, "tests", "helpers", "_build", binary)
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "helpers"), "_build/crew_selftest"], check=True, timeout=600)
+    r = subprocess.run([exe, str(members), str(rounds)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok" and "ThreadSanitizer" not in r.stderr, (r.stdout, r.stderr[-2000:])
+
+
 def test_layout_query_rejects_bad_arguments(mh):
     lib = mh.lib()
     cnt = C.c_ulong()
