@@ -570,8 +570,9 @@ int shard_exchange(murbhip_ctx* c, Shard& sh, int buf, int failed)
                 RC_TRY(nccl_rc(r.Recv(base + (size_t)from * slice_f4, slice_f4 * 4, kRcclFloat, from, sh.comm_rccl, sh.comm)));
             }
             RC_TRY(nccl_rc(r.GroupEnd()));
-        } else
-        RC_TRY(nccl_rc(rccl().AllGather(base + (size_t)sh.rank * slice_f4, base, slice_f4 * 4, kRcclFloat, sh.comm_rccl, sh.comm)));
+        } else {
+            RC_TRY(nccl_rc(rccl().AllGather(base + (size_t)sh.rank * slice_f4, base, slice_f4 * 4, kRcclFloat, sh.comm_rccl, sh.comm)));
+        }
     } else {
         if (idle) return 0;
         // pull model: each shard copies every peer's slice out of the peer's buffer
