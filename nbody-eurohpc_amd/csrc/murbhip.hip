@@ -341,9 +341,12 @@ Plan make_plan(const murbhip_ctx* c)
         // tools/solo_profile.py: N=200k, W=2/4/8 -> split 2/4/4 is best)
         const long items = sym_items_per_rank(c);
         const long want = (c->world > 1 ? 16L : 8L) * 4 * std::max(c->cu_count, 1);
+        // ... and with few block pairs per rank finer still, so that each of the three launches of a step gets its round of
+        // workgroups (tools/solo_rank.py, round 3: N=100k W=8, 689 block pairs: split 8 beats 4 by 3 %; N=60k W=4, 465: by 4.6 %;
+        // N=30k W=2, 240: split 16 beats 4 by 5.5 %; from ~1000 block pairs up 4 is best: N=100k W=4, N=200k W=8)
         p.split = (c->jsplit == 1 || c->jsplit == 2 || c->jsplit == 4 || c->jsplit == 8 || c->jsplit == 16)
                       ? c->jsplit
-                      : (items >= want ? 1 : (2 * items >= want ? 2 : 4));
+                      : (items >= want ? 1 : (2 * items >= want ? 2 : (c->world == 1 || items >= 1000 ? 4 : (items >= 400 ? 8 : 16))));
         // One GPU below 45 000 bodies (BASELINE's N = 30 000: 465 block pairs for 1024 workgroup slots): 8-wave
         // workgroups (2 per SIMD, 2 workgroups per CU: a CU's last workgroup still has two waves per SIMD to interleave),
         // quarter-block items with the last 30 % of the launch cut finer, diagonal blocks as triangular pieces.
