@@ -198,6 +198,7 @@ def test_bench_py_with_several_ranks(gpu, world, n):
     assert set(oc) == {30000, 60000}
     for e in oc.values():
         assert e["other_plan"]["kernel_variant"] == (1 if e["plan"]["kernel_variant"] == 8 else 8) and e["other_plan"]["ms_per_step"] > 0
+        assert e["exchange"]["all_gather_ms_avg"] > 0 and (e["exchange"]["reduce_scatter_ms_avg"] > 0) == (e["plan"]["kernel_variant"] == 8)
         assert e["value"] > 0 and e["roofline"]["kernel_ms_avg"] > 0 and abs(e["value"] - float(e["n_bodies"]) ** 2 * e["steps"] / (e["ms_per_step"] * e["steps"] * 1e-3)) / e["value"] < 1e-6
     assert oc[60000]["plan"]["kernel_variant"] == 8 or world == 4     # a rank of 4 at 60 000 bodies falls back to the one-sided plan
     assert "environment" not in d
