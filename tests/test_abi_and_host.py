@@ -303,6 +303,40 @@ def test_shard_crew_selftest(binary, members, rounds):
     assert r.returncode == 0 and r.stdout.strip() == "ok" and "ThreadSanitizer" not in r.stderr, (r.stdout, r.stderr[-2000:])
 
 
+def test_bench_host_facts_and_roofline_arithmetic():
+    """bench.py without a GPU: the host's share is read at import, BEFORE OpenMP can narrow the main thread's affinity mask
+    (usable cores = physical cores in the mask, capped by the cgroup CPU quota) and becomes the CPU baseline's thread count; and
+    the roofline arithmetic of a measurement (interactions per launch from the library: N^2 / passes under the multi-pass
+    evaluation; (N / ranks) x N over the launches of a step for several ranks)."""
+    code = (
+        "import json, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "m = {'info': {'variant': 8}, 'force_launches': 30, 'steps': 10, 'interactions_per_launch': 3.6e9 / 3, 'force_ms_avg': 0.2, 'events': 'x'}\n"
+        "one = bench.roofline_of(m, 60000, 1, 157.2864)\n"
+        "m2 = dict(m, force_launches=60, steps=20, force_ms_avg=0.25)\n"
+        "many = bench.roofline_of(m2, 200000, 8, 157.2864)\n"
+        "print(json.dumps({'host': bench.HOST, 'omp': os.environ['OMP_NUM_THREADS'], 'ipc': os.environ['HSA_ENABLE_IPC_MODE_LEGACY'], 'one': one, 'many': many}))\n"
+    ) % ROOT
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    h = d["host"]
+    assert 1 <= h["cpus_usable"] <= h["physical_cores_in_mask"] <= h["cpus_in_affinity_mask"] <= h["logical_cpus"] and h["model"]
+    assert h["cpus_in_affinity_mask"] == len(os.sched_getaffinity(0))
+    if h["cgroup_cpu_quota"]:
+        assert h["cpus_usable"] <= max(1, int(h["cgroup_cpu_quota"] + 1e-9))
+    assert d["omp"] == str(h["cpus_usable"]) and d["ipc"] == "0"
+    one, many = d["one"], d["many"]
+    assert one["bound"] == "valu" and one["launches_per_step"] == 3 and abs(one["interactions_per_launch"] - 1.2e9) < 1
+    assert abs(one["achieved"] - 20 * 1.2e9 / 0.2e-3 / 1e12) < 1e-9 and abs(one["frac"] - one["achieved"] / 157.2864) < 1e-12
+    assert abs(one["frac_executed"] - one["frac"] * 13 / 20) < 1e-12
+    assert abs(many["interactions_per_launch"] - 25000.0 * 200000.0 / 3) < 1 and many["launches_per_step"] == 3
+
+
 def test_planner_selftest_under_sanitizers():
     """The host-side planner (csrc/murb_plan.h, murb_schedule.h: item tables and partial-row layouts, no HIP in them)
     compiled with g++ under AddressSanitizer + UBSan and swept over a few thousand plans (sizes 1 … 60 001, 1-8 ranks, splits,
