@@ -189,12 +189,19 @@ int murbhip_sync(murbhip_ctx* ctx);
 
 /* Mechanical energy of the current state: kinetic = sum 1/2 m v^2, potential = -1/2 sum_i sum_{j != i}
  * G m_i m_j / sqrt(r_ij^2 + soft^2) — the per-iteration metric of the reference's gpu+tracking
- * implementation (SimulationNBodyCUDAPropertyTracking.cu:217-304, summed there with cub).  One N^2
- * potential sweep on the device, then the per-body terms summed in fp64 on the device (256-body block sums
- * in a fixed order; the host adds the few hundred block rows); waits for enqueued steps.  In rank
- * mode the values cover the caller's own bodies only (sum them over ranks), and under the pair-symmetric plan the call
- * is a collective (every rank evaluates its half-ring share of the pair terms, one reduce-scatter): all ranks must make it.  The accelerations of the
- * last evaluation (murbhip_download_acc) are left alone. */
+ * implementation (SimulationNBodyCUDAPropertyTracking.cu:217-304, summed there with cub).
+ * Pair-symmetric plan (round 3): the potential comes out of a FORCE evaluation — two more packed instructions per 18 sum
+ * G m_i G m_j / r of every pair a wave meets, one float per group of 4 i bodies behind the partial rows, fp64 from there on —
+ * so there is no second N^2 sweep; the forces of that evaluation are remembered (bit-identical to a plain evaluation's),
+ * and a step that follows directly only launches the state update (with several shards: state update + position
+ * exchange).  A tracked iteration (energy, then step: `--im hip+tracking`) therefore costs ONE force evaluation: 7.4 ms
+ * instead of 10.0 at N = 200 000.  In rank mode the potential covers the PAIRS this rank evaluated under the half-ring
+ * schedule, the kinetic energy its own bodies: sum both over the ranks; the call is a collective (the force evaluation
+ * contains the reduce-scatter) unless the forces of the current positions are already remembered.
+ * One-sided plan (small N), several passes (N > 2.4 M) or option "energy_sweep" 1: one N^2 potential sweep on the device
+ * (phi_i = sum_j G m_j / r), then -1/2 sum m_i phi_i; values cover the caller's own bodies.
+ * The per-body terms are summed in fp64 on the device (256-body block sums in a fixed order; the host adds the few hundred
+ * block rows); waits for enqueued steps. */
 int murbhip_energy(murbhip_ctx* ctx, double* kinetic, double* potential);
 
 /* First moments of the current state, fp64 sums (on the device, like murbhip_energy) over the caller's own bodies:
@@ -235,6 +242,8 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  *   "tri_div"        variant 8, several ranks: the items of the own-slice triangle's two launches (which run under the two
  *                    collectives and, with few blocks per slice, do not fill the chip) cut into 1, 2, 4 or 8 parts more
  *                    than the rectangles' items; 0 (default) = the plan's choice (~2 rounds of workgroups per launch)
+ *   "energy_sweep"   murbhip_energy on a pair-symmetric plan: 1 = the separate potential sweep of rounds 1-2 instead of the
+ *                    pair potential summed inside a force evaluation (default 0); kept for the A/B and as a cross-check
  *   "xcd_order"      variant 8: 0 (default) = j-major item order (round-robin dispatch then gives XCD x the i
  *                    blocks x mod 8 of every j block); 1 = one contiguous run of items per XCD (measured:
  *                    more L2 misses, same time; kept for the comparison)
@@ -288,7 +297,9 @@ int murbhip_set_option(murbhip_ctx* ctx, const char* key, long value);
  *       wait_gather | wait_reduce (compute stream idle, waiting for that collective), step (compute stream, first launch of
  *       a step to the end of its state update); the last five need "profile" 2
  *   "compute_wait_ms_per_step"                              (wait_gather + wait_reduce) per profiled step
- *   "spans_dropped"                                         1 when the event pool (4096 spans per shard) ran out */
+ *   "spans_dropped"                                         1 when the event pool (4096 spans per shard) ran out
+ *   "sym_launches"                                          pair-symmetric launches of any form (force, force + pair potential,
+ *                                                           potential sweep) since "profile" was last set */
 int murbhip_get_info(murbhip_ctx* ctx, const char* key, double* value);
 
 #ifdef __cplusplus

@@ -125,6 +125,40 @@ __device__ __forceinline__ void murb_interact_sym(const murb_f2 xj, const murb_f
     ajz = __builtin_elementwise_fma(fj, dz, ajz);
 }
 
+// force + pair potential (PHI = 2): the same operations in the same order as murb_interact_sym (the forces of a tracked
+// evaluation are bit-identical to an untracked one) plus G m_i G m_j / r of the pair summed per lane: two more packed
+// instructions (three in the triangular form of a diagonal item, which keeps the masked and the unmasked sum apart: the
+// pairs of a piece's own step are met from both sides, with only the i side applied).  What the tracked metrics need is the
+// TOTAL potential energy, not a potential per body: one float per group of 4 i bodies instead of a second N^2 sweep.
+template <int DYN>
+__device__ __forceinline__ void murb_interact_sym_pe(const murb_f2 xj, const murb_f2 yj, const murb_f2 zj, const murb_f2 gj,
+                                                     const float xi, const float yi, const float zi, const float gi, const float gi_raw,
+                                                     const float soft2, murb_f2& aix, murb_f2& aiy, murb_f2& aiz,
+                                                     murb_f2& ajx, murb_f2& ajy, murb_f2& ajz, murb_f2& pe_both, murb_f2& pe_all)
+{
+    const murb_f2 dx = xj - xi;
+    const murb_f2 dy = yj - yi;
+    const murb_f2 dz = zj - zi;
+    murb_f2 r2 = __builtin_elementwise_fma(dx, dx, (murb_f2)(soft2));
+    r2 = __builtin_elementwise_fma(dy, dy, r2);
+    r2 = __builtin_elementwise_fma(dz, dz, r2);
+    murb_f2 inv;
+    inv.x = __builtin_amdgcn_rsqf(r2.x);
+    inv.y = __builtin_amdgcn_rsqf(r2.y);
+    const murb_f2 inv3 = (inv * inv) * inv;
+    const murb_f2 fi = gj * inv3;          // pull of j on i
+    const murb_f2 fj = inv3 * (-gi);       // pull of i on j (opposite direction)
+    const murb_f2 gg = gj * inv;           // G m_j / r
+    pe_both = __builtin_elementwise_fma(gg, (murb_f2)(gi), pe_both);
+    if (DYN) pe_all = __builtin_elementwise_fma(gg, (murb_f2)(gi_raw), pe_all);
+    aix = __builtin_elementwise_fma(fi, dx, aix);
+    aiy = __builtin_elementwise_fma(fi, dy, aiy);
+    aiz = __builtin_elementwise_fma(fi, dz, aiz);
+    ajx = __builtin_elementwise_fma(fj, dx, ajx);
+    ajy = __builtin_elementwise_fma(fj, dy, ajy);
+    ajz = __builtin_elementwise_fma(fj, dz, ajz);
+}
+
 // potential form: phi_i += G m_j / r, phi_j += G m_i / r (8 packed + 2 rsq per i x j-pair)
 __device__ __forceinline__ void murb_interact_sym_phi(const murb_f2 xj, const murb_f2 yj, const murb_f2 zj, const murb_f2 gj,
                                                       const float xi, const float yi, const float zi, const float gi,
@@ -153,17 +187,22 @@ __device__ __forceinline__ void murb_interact_sym_phi(const murb_f2 xj, const mu
 template <int WAVES, int ILOAD, int PHI, int RED, int DYN>
 __device__ __forceinline__ void murb_sym_walk(const MurbSymArgs& a, const float4* tileA, const float4* tileB, float* stage,
                                               const int lane, const int wave, const int groups_per_wave,
-                                              const unsigned int i_block_slot, const unsigned long out_off, const int p_first,
+                                              const unsigned int i_block_slot, const unsigned long out_off, const int out_stride,
+                                              const float pe_scale, const int p_first,
                                               const int p_sym, murb_f2 (&ajx)[MURB_SYM_STEPS], murb_f2 (&ajy)[MURB_SYM_STEPS],
                                               murb_f2 (&ajz)[MURB_SYM_STEPS])
 {
     constexpr int R = MURB_SYM_R;
+    // PHI = 2 (needs RED = 1): a 13th value per group, the group's pair potential, takes the same way out as the 12 i-side
+    // sums — staged, summed over the wave by a team of four lanes, stored (out_off / out_stride point the team at the
+    // potential's own area behind the three components: one float per group)
+    constexpr int NV = PHI == 2 ? 13 : 12;
     const float soft2 = a.soft2;
     // staging rows of 64 floats at a stride of 80: lane L writes entry L (64 consecutive floats: no bank conflict); team lane
     // q of value k reads the four float4 at entries 16 m + 4 q (m = 0..3): the eight lanes served together (two values x
     // four q) start 4 floats apart within a row and the odd row is 80 = 16 (mod 32) floats further: 32 distinct banks
     const int stage_wr = lane;
-    const int stage_rd = ((lane >> 2) < 12 ? (lane >> 2) : 11) * 80 + (lane & 3) * 4;
+    const int stage_rd = ((lane >> 2) < NV ? (lane >> 2) : NV - 1) * 80 + (lane & 3) * 4;
     // RED = 1: four lanes per value add up its 64 staged entries
     const auto team_sum = [&](int g_of) {
         const float4* src = reinterpret_cast<const float4*>(stage + stage_rd);
@@ -175,7 +214,7 @@ __device__ __forceinline__ void murb_sym_walk(const MurbSymArgs& a, const float4
         float z = s2.x + s2.y;
         z += murb_dpp<0xB1>(z);                               // quad_perm [1,0,3,2]
         z += murb_dpp<0x4E>(z);                               // quad_perm [2,3,0,1]
-        a.part[(unsigned long)out_off + g_of * R] = z;
+        a.part[(unsigned long)out_off + (unsigned long)(g_of * out_stride)] = z;
     };
 #pragma unroll 1
     for (int gk = 0; gk < groups_per_wave; ++gk) {
@@ -221,6 +260,7 @@ __device__ __forceinline__ void murb_sym_walk(const MurbSymArgs& a, const float4
         murb_f2 aix[R], aiy[R], aiz[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { aix[r] = (murb_f2)(0.f); aiy[r] = (murb_f2)(0.f); aiz[r] = (murb_f2)(0.f); }
+        murb_f2 pe_both = (murb_f2)(0.f), pe_all = (murb_f2)(0.f);   // PHI = 2: this group's pair potential (chains of 32 terms)
 
 #pragma unroll
         for (int p = 0; p < MURB_SYM_STEPS; ++p) {
@@ -235,6 +275,9 @@ __device__ __forceinline__ void murb_sym_walk(const MurbSymArgs& a, const float4
                     const float gie = DYN ? murb_masked(gi[r], both) : gi[r];
                     if constexpr (PHI == 1)
                         murb_interact_sym_phi(xj, yj, zj, gj, xi[r], yi[r], zi[r], gie, soft2, aix[r], ajx[p]);
+                    else if constexpr (PHI == 2)
+                        murb_interact_sym_pe<DYN>(xj, yj, zj, gj, xi[r], yi[r], zi[r], gie, gi[r], soft2, aix[r], aiy[r], aiz[r], ajx[p],
+                                                  ajy[p], ajz[p], pe_both, pe_all);
                     else
                         murb_interact_sym(xj, yj, zj, gj, xi[r], yi[r], zi[r], gie, soft2, aix[r], aiy[r], aiz[r], ajx[p], ajy[p],
                                           ajz[p]);
@@ -259,6 +302,16 @@ __device__ __forceinline__ void murb_sym_walk(const MurbSymArgs& a, const float4
         } else {
 #pragma unroll
             for (int k = 0; k < 12; ++k) stage[k * 80 + stage_wr] = v[k];
+            if constexpr (PHI == 2) {
+                // off the diagonal every pair is met once.  A diagonal item in its plain form meets every ordered pair of the
+                // block (and every body itself): half of it (pe_scale).  In its triangular form: the later steps once
+                // (pe_both), the own step from both sides (pe_all - pe_both): half of that.  The self terms (G m_i)^2 / soft
+                // the halves still contain are taken out on the host.
+                float pg = pe_both.x + pe_both.y;
+                if (DYN) pg = 0.5f * (pg + (pe_all.x + pe_all.y));
+                else pg *= pe_scale;
+                stage[12 * 80 + stage_wr] = pg;
+            }
             team_sum(g);
         }
     }
@@ -272,6 +325,8 @@ __device__ __forceinline__ void murb_sym_walk(const MurbSymArgs& a, const float4
 // ILOAD = 1 (what the library launches): the i bodies come through scalar loads (s_load_dwordx4 from the
 // constant address space, 4 per group) instead of 4 vector loads + 16 v_readfirstlane: 16 VALU issue slots
 // less per group of 576, +2.1 % at N=200k and +2.7 % at 30k, bit-identical results.  ILOAD = 0 keeps the vector-load form.
+// PHI = 2: force + pair potential in one pass (murb_interact_sym_pe; RED = 1 only): what murbhip_energy runs on a
+// pair-symmetric plan.  The buffer then has room for one more float per group behind its three components.
 // PHI = 1: the same sweep for the potential (murbhip_energy): phi instead of the three acceleration components,
 // written to component 0 only (the cells of components 1 and 2 keep whatever they held; their row sums are not used).
 // RED = 0: the 12 i-side sums of a group are folded in registers (murb_reduce12: 39 VALU instructions).  RED = 1: through
@@ -324,21 +379,26 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const 
 
     // where this lane's i-side total goes: value idx(lane) = 3 * body + component (see murb_reduce12)
     unsigned long out_off;
+    int out_stride = MURB_SYM_R;   // floats between two groups' totals
     {
         const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
         int idx = b2 ? 8 + 2 * b4 + b5 : 4 * b3 + 2 * b4 + b5;
         if constexpr (RED != 0) idx = (lane >> 2) < 12 ? (lane >> 2) : 11;   // team of four lanes per value; lanes 48-63 repeat value 11
         const int r = idx / 3, c = idx - 3 * r;
         out_off = (unsigned long)c * a.comp_stride + it.ioff + r;
+        if constexpr (PHI == 2) {   // lanes 48-63: the group's pair potential, one float per group behind the three components
+            static_assert(RED == 1, "the pair potential leaves through the LDS team reduction");
+            if ((lane >> 2) >= 12) { out_off = 3ul * a.comp_stride + it.ioff / MURB_SYM_R; out_stride = 1; }
+        }
     }
     // RED = 1: this wave's staging area (12 rows of 64 floats at a stride of 80)
-    float* const stage = reinterpret_cast<float*>(&scratch[0][0][0]) + wave * (12 * 80);
+    float* const stage = reinterpret_cast<float*>(&scratch[0][0][0]) + wave * ((PHI == 2 ? 13 : 12) * 80);
     if (triangular)
         murb_sym_walk<WAVES, ILOAD, PHI, RED, 1>(a, tileA, tileB, stage, lane, wave, groups_per_wave, (unsigned int)i_item_slot, out_off,
-                                                 p_first, p_sym, ajx, ajy, ajz);
+                                                 out_stride, 1.f, p_first, p_sym, ajx, ajy, ajz);
     else
         murb_sym_walk<WAVES, ILOAD, PHI, RED, 0>(a, tileA, tileB, stage, lane, wave, groups_per_wave, (unsigned int)i_item_slot, out_off,
-                                                 0, 0, ajx, ajy, ajz);
+                                                 out_stride, no_j_side ? 0.5f : 1.f, 0, 0, ajx, ajy, ajz);
 
     // j side: fold the waves pairwise in a fixed order (WAVES = 4: 3+2 -> 1+0 -> 0), wave 0 writes the item's j row
     if (!no_j_side) {
@@ -371,7 +431,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const 
 #pragma unroll
             for (int p = 0; p < MURB_SYM_STEPS; ++p) {
                 px[p * 64 + lane] = ajx[p];
-                if constexpr (PHI == 0) {
+                if constexpr (PHI != 1) {
                     py[p * 64 + lane] = ajy[p];
                     pz[p * 64 + lane] = ajz[p];
                 }
@@ -509,6 +569,23 @@ __global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_integrate
     float* wa = reinterpret_cast<float*>(a.vel + va);
     float* wb = reinterpret_cast<float*>(a.vel + va + MURB_TILE_PAIRS);
     wa[h] = vx; wa[2 + h] = vy; wb[h] = vz;
+}
+
+// Sum of the groups' pair potentials of a set of launches (PHI = 2: `count` floats behind the three components of the partial
+// rows, zero where no item has groups) in fp64, in a fixed order: thread t adds entries t, t + 1024 x blocks, ...; every
+// workgroup folds its 1024 partial sums through LDS and writes one double; the host adds the few hundred of them.
+__global__ __launch_bounds__(1024) void murb_sym_pe_sum_kernel(const float* pe, unsigned long count, double* out)
+{
+    __shared__ double red[1024];
+    double acc = 0.0;
+    for (unsigned long k = (unsigned long)blockIdx.x * 1024 + threadIdx.x; k < count; k += 1024ul * gridDim.x) acc += (double)pe[k];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int half = 512; half >= 1; half >>= 1) {
+        if ((int)threadIdx.x < half) red[threadIdx.x] += red[threadIdx.x + half];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
 // Point-to-point form of the reduce-scatter ("exchange_p2p"): out = this rank's own contribution to its slice + the chunks

@@ -70,6 +70,7 @@ struct SymSet {
     float* part = nullptr;
     size_t comp_stride = 0;           // floats per component (single pass)
     MurbSymBlockRows* rows = nullptr; // device copy of the table
+    double* pe_sums = nullptr;        // murbhip_energy: the workgroups' partial sums of the set's pair potentials [kPeSumBlocks]
     int nblocks = 0;                  // entries (all passes)
     std::vector<SymPass> passes;      // more than one entry: multi-pass evaluation
 };
@@ -114,10 +115,12 @@ struct Shard {
     std::vector<hipEvent_t> prof;   // pool of timing events ("profile"): two per recorded span
     size_t prof_used = 0;
     std::vector<int> prof_kind;     // what span k (events 2k, 2k+1) brackets: ProfKind
+    unsigned long sym_launches = 0; // pair-symmetric launches of any form since "profile" was last set (force, potential sweep)
     size_t bytes = 0;
 };
 
 constexpr int kMaxParts = 64;          // rows of the partial-sum buffer
+constexpr int kPeSumBlocks = 256;      // workgroups of murb_sym_pe_sum_kernel
 constexpr size_t kProfPairs = 4096;
 
 // What a pair of timing events brackets.  "profile" 1: the force launches only (two event records per launch);
@@ -162,6 +165,8 @@ struct murbhip_ctx {
     bool lf_half = false;     // leapfrog: device velocities lag the positions by half a step of lf_last_dt
     // acceleration cache: murbhip_compute_acc / a leapfrog read-out evaluated the forces at the CURRENT positions
     bool acc_current = false;        // acc_out holds them (a second evaluation would be bit-identical: skip it)
+    bool want_pe = false;            // the force launches being enqueued also sum the pair potential (murbhip_energy)
+    bool pe_current = false;         // ... and the partial-row buffers hold it for the current positions
     float lf_last_dt = 0.f;
     int force_exchange = 0;   // run the exchange even with one rank (self-test of the RCCL binding)
     int taper = -1;           // pair-symmetric kernel: % of each launch cut into finer items (-1 = the plan's default)
@@ -169,6 +174,7 @@ struct murbhip_ctx {
     long sym_pass_mb = 0;     // ... one GPU: budget (MiB) for the partial rows of one pass; 0 = a quarter of the device memory
     int sym_red = -1;         // ... i-side reduction in registers (0) or through LDS (1) (-1 = the plan's default)
     int init_libm_fma = -1;   // murbhip_init_bodies: which build of glibc's sincosf to reproduce (-1 = what this host's libm picks)
+    int energy_sweep = 0;     // murbhip_energy on a pair-symmetric plan: 1 = the separate potential sweep of rounds 1-2 (kept for the A/B)
     int exchange_p2p = 0;     // RCCL exchange by grouped ncclSend/ncclRecv instead of ncclReduceScatter / ncclAllGather
     int tri_div = 0;          // ... exchange pipeline: the own-slice triangle's items cut into this many parts more (0 = the plan's choice)
     int pad_aware = 1;        // ... 1: padding slots are not walked (murb_schedule.h, sym_orient); 0: every block as if full (A/B)
@@ -610,7 +616,7 @@ int ensure_accp(murbhip_ctx* c, Shard& sh)
 
 void free_sym_set(SymSet& st)
 {
-    hipFree(st.part); hipFree(st.rows);
+    hipFree(st.part); hipFree(st.rows); hipFree(st.pe_sums);
     st = SymSet{};
 }
 
@@ -619,8 +625,11 @@ int upload_sym_set(Shard& sh, SymSet& st, const std::vector<MurbSymBlockRows>& t
     st.comp_stride = floats;
     st.nblocks = (int)table.size();
     if (floats == 0) return 0;
-    const size_t bytes = 3 * floats * sizeof(float);
+    // three components, and behind them one float per group of 4 i bodies for the pair potential of a tracked evaluation
+    // (murb_kernels_sym.h, PHI = 2: entry ioff / 4 + group; zero wherever no item has groups)
+    const size_t bytes = (3 * floats + floats / MURB_SYM_R + 1) * sizeof(float);
     HIP_TRY(hipMalloc((void**)&st.part, bytes));
+    HIP_TRY(hipMalloc((void**)&st.pe_sums, kPeSumBlocks * sizeof(double)));
     HIP_TRY(hipMemsetAsync(st.part, 0, bytes, sh.compute));   // every cell has a writer; zero anyway (on OUR stream: non-blocking w.r.t. stream 0)
     HIP_TRY(hipMalloc((void**)&st.rows, table.size() * sizeof(MurbSymBlockRows)));
     HIP_TRY(hipMemcpy(st.rows, table.data(), table.size() * sizeof(MurbSymBlockRows), hipMemcpyHostToDevice));
@@ -732,6 +741,7 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
 {
     if (count <= 0) return 0;
     if (!stream) stream = sh.compute;
+    ++sh.sym_launches;
     const SymSet& st = own_triangle_rows ? sh.sym_tri : sh.sym_main;
     MurbSymArgs sa{};
     sa.rec = sh.rec[c->cur];
@@ -740,6 +750,7 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
     sa.items = sh.sym_items;
     sa.item_first = first;
     sa.soft2 = c->soft2;
+    const bool with_pe = !potential && c->want_pe;           // force + pair potential in one pass (murb_kernels_sym.h, PHI = 2)
     const bool timed = stream == sh.compute && !potential;   // the profiling events live on the main compute stream
     int rc_span = 0;
     const int sp = timed ? span_begin(c, sh, kind, stream, &rc_span) : -1;
@@ -747,10 +758,12 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
     const dim3 grid((unsigned)count);
     if (sh.sym_waves == 8) {
         if (potential) hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1, 1>), grid, dim3(512), 0, stream, sa);
+        else if (with_pe) hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1, 2, 1>), grid, dim3(512), 0, stream, sa);
         else if (sh.sym_red == 1) hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1, 0, 1>), grid, dim3(512), 0, stream, sa);
         else hipLaunchKernelGGL((murb_force_sym_kernel<4, 8, 1>), grid, dim3(512), 0, stream, sa);
     } else {
         if (potential) hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1, 1>), grid, dim3(256), 0, stream, sa);
+        else if (with_pe) hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1, 2, 1>), grid, dim3(256), 0, stream, sa);
         else if (sh.sym_red == 1) hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1, 0, 1>), grid, dim3(256), 0, stream, sa);
         else hipLaunchKernelGGL((murb_force_sym_kernel<4, 4, 1>), grid, dim3(256), 0, stream, sa);
     }
@@ -966,7 +979,7 @@ int shard_iteration_plain(murbhip_ctx* c, Shard& sh, const Plan& p, float dt, in
     const bool exchange = update_state && (c->world > 1 || c->force_exchange);
     int rc = 0;
     if (!is_idle(c, sh)) rc = [&]() -> int {   // timing aid: see "solo_shard"
-        if (c->world == 1) {
+        if (c->world == 1 || reuse) {   // reuse: the forces at these positions are in acc_out, only the update is left
             if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
             if (!reuse) RC_TRY(enqueue_force(c, sh, p, 0));
         } else if (c->overlap) {
@@ -992,25 +1005,29 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
     // forces at the current positions are already in acc_out (compute_acc, or a leapfrog read-out, just ran): an
     // evaluation needs nothing at all, a state update (one shard, no exchange) only the integrate launch
     const bool have_acc = c->acc_current;
+    const bool have_pe = c->pe_current;
     c->acc_current = false;
-    if (have_acc && !update_state) { c->acc_current = true; return 0; }
-    const bool reuse = have_acc && c->world == 1 && !c->force_exchange && c->solo_shard < 0;
+    c->pe_current = false;
+    if (have_acc && !update_state && (!c->want_pe || have_pe)) { c->acc_current = true; c->pe_current = have_pe; return 0; }
     const bool exchanging = c->world > 1 || c->force_exchange;
+    // ... with several shards: the integrate launch from the remembered forces and the position exchange
+    const bool reuse = have_acc && update_state && c->solo_shard < 0;
     if (p.symmetric) {
         bool stale = false;
         for (const Shard& sh : c->shards) stale = stale || (sh.sym_items && sym_schedule_stale(c, sh, p));
         if (stale) RC_TRY(murbhip_sync(c));   // tables are rebuilt below: nothing may be in flight
     }
-    if (p.symmetric && exchanging)
+    if (p.symmetric && exchanging && !reuse)
         RC_TRY(crew_run(c, [&](Shard& sh) { return shard_iteration_sym_multi(c, sh, p, dt, update_state); }));
     else
         RC_TRY(crew_run(c, [&](Shard& sh) { return shard_iteration_plain(c, sh, p, dt, update_state, reuse); }));
-    if (p.symmetric && exchanging) c->reduce_pending = true;
+    if (p.symmetric && exchanging && !reuse) c->reduce_pending = true;
     if (update_state) {
         if (exchanging) c->gather_pending = true;
         c->cur ^= 1;
     } else {
         c->acc_current = true;
+        c->pe_current = c->want_pe && p.symmetric;
     }
     return 0;
 }
@@ -1669,6 +1686,53 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
 {
     if (!c || !kinetic || !potential) return MURBHIP_E_INVALID;
     if (!c->uploaded) return MURBHIP_E_STATE;
+    const Plan main_plan = make_plan(c);
+    bool one_pass = true;
+    for (const Shard& sh : c->shards) one_pass = one_pass && sh.sym_main.passes.size() <= 1;
+    if (main_plan.symmetric && !c->energy_sweep && one_pass) {
+        // Pair-symmetric plan: the potential energy comes out of a FORCE evaluation (murb_kernels_sym.h, PHI = 2: two more
+        // packed instructions per 18 sum G m_i G m_j / r of every pair a wave meets, one float per group of 4 i bodies behind
+        // the partial rows) — no second N^2 sweep.  The forces of that evaluation are remembered, so a step that follows only
+        // launches the state update (also with several shards): a tracked iteration costs one force evaluation.  Every shard
+        // sums the pairs IT evaluated; a body's self term (G m_i)^2 / soft, half of which the diagonal items leave in, goes
+        // out with the shard's own bodies.  (Several passes over one shared buffer, N > 2.4 M: the separate sweep below.)
+        if (!(c->acc_current && c->pe_current)) {
+            c->acc_current = false;   // forces alone are not enough: evaluate again, this time with the pair potential
+            c->want_pe = true;
+            const int rc = enqueue_iteration(c, 0.f, 0);
+            c->want_pe = false;
+            RC_TRY(rc);
+        }
+        bool still_one_pass = true;   // the evaluation above may have built the tables for the first time
+        for (const Shard& sh : c->shards) still_one_pass = still_one_pass && sh.sym_main.passes.size() <= 1;
+        if (still_one_pass) {
+            for (Shard& sh : c->shards) {
+                HIP_TRY(hipSetDevice(sh.device));
+                for (SymSet* st : {&sh.sym_main, &sh.sym_tri}) {
+                    if (!st->part) continue;
+                    hipLaunchKernelGGL(murb_sym_pe_sum_kernel, dim3(kPeSumBlocks), dim3(1024), 0, sh.compute, st->part + 3 * st->comp_stride,
+                                       (unsigned long)(st->comp_stride / MURB_SYM_R + 1), st->pe_sums);
+                    RC_TRY(hip_rc(hipGetLastError()));
+                }
+            }
+            double sums[MURB_METRIC_VALUES];
+            RC_TRY(device_metrics(c, false, sums));   // syncs
+            double pair_sum = 0.0, part[kPeSumBlocks];
+            for (Shard& sh : c->shards) {
+                HIP_TRY(hipSetDevice(sh.device));
+                for (SymSet* st : {&sh.sym_main, &sh.sym_tri}) {
+                    if (!st->part) continue;
+                    HIP_TRY(hipMemcpy(part, st->pe_sums, sizeof part, hipMemcpyDeviceToHost));
+                    for (double v : part) pair_sum += v;
+                }
+            }
+            const double g = (double)c->g;
+            *kinetic = sums[0];
+            *potential = -pair_sum / g + 0.5 * g / std::sqrt((double)c->soft2) * sums[12];
+            return 0;
+        }
+        c->pe_current = false;   // several passes after all: fall through to the sweep (the forces stay remembered)
+    }
     // phi_i = sum_j GM_j / sqrt(r_ij^2 + soft^2) over ALL j (self term included), written to the x plane of phi_out:
     // pair-symmetric sweep where the force plan is pair-symmetric (one GPU: one launch; several ranks: the half-ring
     // schedule with its reduce-scatter), the one-sided sweep otherwise
@@ -1682,7 +1746,6 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
     }
     // one shard on the pair-symmetric plan: the sweep is pair-symmetric too (phi_i += G m_j / r, phi_j += G m_i / r:
     // 8 packed + 2 rsq per 4 pair terms instead of 7 + 2 per 2), through the force kernel's partial rows
-    const Plan main_plan = make_plan(c);
     const bool symmetric_sweep = main_plan.symmetric && c->world == 1 && !c->force_exchange;
     const bool symmetric_multi = main_plan.symmetric && !symmetric_sweep;   // several ranks: the half-ring form
     for (Shard& sh : c->shards) {
@@ -1753,6 +1816,7 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     else if (k == "jsplit") { if (value < 0 || value > kMaxParts / 2) return MURBHIP_E_INVALID; c->jsplit = (int)value; }
     else if (k == "xcd_order") c->xcd_order = value ? 1 : 0;
     else if (k == "pad_aware") c->pad_aware = value ? 1 : 0;
+    else if (k == "energy_sweep") c->energy_sweep = value ? 1 : 0;
     else if (k == "exchange_p2p") {
         if (value && (c->exchange != 1 || !rccl().Send || !rccl().Recv)) return MURBHIP_E_STATE;   // needs the RCCL exchange and ncclSend/ncclRecv
         RC_TRY(murbhip_sync(c));
@@ -1802,6 +1866,7 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
                 for (hipEvent_t& e : sh.prof) HIP_TRY(hipEventCreate(&e));
             }
             sh.prof_used = 0;
+            sh.sym_launches = 0;
         }
     } else return MURBHIP_E_INVALID;
     return 0;
@@ -1829,6 +1894,7 @@ int murbhip_get_info(murbhip_ctx* c, const char* key, double* value)
     else if (k == "variant") *value = p.variant;
     else if (k == "interactions_per_launch") *value = c->interactions_per_launch;
     else if (k == "device_bytes") { double b = 0; for (Shard& sh : c->shards) b += (double)sh.bytes; *value = b; }
+    else if (k == "sym_launches") { double v = 0; for (Shard& sh : c->shards) v += (double)sh.sym_launches; *value = v; }
     else if (k == "spans_dropped") {   // 1: the event pool ran out during the profiled steps (averages cover the first part only)
         *value = 0;
         for (Shard& sh : c->shards) if (!sh.prof.empty() && sh.prof_used + 2 > sh.prof.size()) *value = 1;

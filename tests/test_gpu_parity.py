@@ -204,8 +204,10 @@ def test_multi_pass_evaluation(gpu, O, n, budget_mb, opts):
         # same partial sums, fp64 additions regrouped; with "xcd_order" the single-pass run keeps the interleaved item order
         # (other tail items, other partial sums) while the passes fall back to the j-major one: fp32 noise between them
         assert O.rel_err(multi.acc(), one.acc()).max() <= (6e-7 if opts.get("xcd_order") else 2e-7)
+        # the single-pass run takes the pair potential out of its force evaluation, the multi-pass one (one shared row buffer)
+        # runs the separate potential sweep: two fp32 evaluations of the same sum, each within ~2e-7 of the fp64 value
         (k1, p1), (k2, p2) = one.energy(), multi.energy()
-        assert abs(p2 - p1) <= 1e-7 * abs(p1) and abs(k2 - k1) <= 1e-7 * abs(k1)
+        assert abs(p2 - p1) <= 5e-7 * abs(p1) and abs(k2 - k1) <= 1e-7 * abs(k1)
         one.steps(DT, 3); multi.steps(DT, 3)
         one.sync(); multi.sync()
         s1, s2 = one.state(), multi.state()
@@ -957,13 +959,16 @@ def test_file_scheme_end_to_end(gpu, O, tmp_path, monkeypatch):
         assert np.array_equal(bits(moved[k]), bits(ref[k])), k
 
 
-@pytest.mark.parametrize("n", [4000, 20000])
+@pytest.mark.parametrize("n,devices", [(4000, [0]), (20000, [0]), (20000, [0, 0, 0]), (9000, [0, 0])])
 @pytest.mark.parametrize("integrator", [0, 1])
-def test_remembered_forces_change_nothing(gpu, O, n, integrator):
+def test_remembered_forces_change_nothing(gpu, O, n, integrator, devices):
     """murbhip_compute_acc() results are remembered (a repeated call, a leapfrog read-out or a directly following
-    step reuse them).  Every mix of calls must land on the bits of the plain sequence."""
+    step reuse them — with several shards too: the step is then the state update and the position exchange only), and
+    murbhip_energy() on a pair-symmetric plan takes the potential out of a force evaluation whose forces are bit-identical
+    to a plain one's.  Every mix of calls must land on the bits of the plain sequence."""
     s = O.init_bodies(n, "galaxy")
-    with gpu.Simulation(n, soft=SOFT) as plain, gpu.Simulation(n, soft=SOFT) as mixed:
+    kw = {"devices": devices} if len(devices) > 1 else {}
+    with gpu.Simulation(n, soft=SOFT, **kw) as plain, gpu.Simulation(n, soft=SOFT, **kw) as mixed:
         for sim in (plain, mixed):
             sim.set_option("integrator", integrator)
             sim.upload(s)
@@ -982,6 +987,40 @@ def test_remembered_forces_change_nothing(gpu, O, n, integrator):
         a, b = plain.state(), mixed.state()
         for k in a:
             assert np.array_equal(bits(a[k]), bits(b[k])), k
+
+
+@pytest.mark.parametrize("scheme,n,devices", [("galaxy", 12001, [0]), ("galaxy", 30000, [0]), ("random", 20000, [0]), ("galaxy", 40000, [0, 0, 0]),
+                                              ("galaxy", 30000, [0, 0])])
+def test_energy_from_the_force_evaluation(gpu, O, scheme, n, devices):
+    """murbhip_energy on a pair-symmetric plan: the potential energy summed inside a FORCE evaluation (one float per group of 4
+    i bodies, fp64 from there on) against the fp64 value and against the separate potential sweep of rounds 1-2
+    ("energy_sweep" 1) — and no second N^2 launch: the tracked sequence energy -> step runs ONE force launch per iteration."""
+    s = O.init_bodies(n, scheme)
+    ke, pe = O.energy_f64(s, SOFT)
+    kw = {"devices": devices} if len(devices) > 1 else {}
+    with gpu.Simulation(n, soft=SOFT, **kw) as fused, gpu.Simulation(n, soft=SOFT, **kw) as sweep:
+        sweep.set_option("energy_sweep", 1)
+        for sim in (fused, sweep):
+            sim.set_option("variant", 8)
+            sim.upload(s)
+        (k1, p1), (k2, p2) = fused.energy(), sweep.energy()
+        assert abs(p1 - pe) <= 5e-7 * abs(pe) and abs(k1 - ke) <= 1e-9 * abs(ke), (p1 - pe) / pe
+        assert abs(p2 - pe) <= 5e-7 * abs(pe) and abs(p1 - p2) <= 5e-7 * abs(pe)
+        # tracked iterations: energy + moments + step.  ONE N^2 evaluation each where the potential rides on the forces (the
+        # step reuses them), two with the separate sweep ("sym_launches" counts pair-symmetric launches of any form)
+        per_force, per_sweep = (1, 1) if len(devices) == 1 else (3, 2)     # several shards: two triangle parts + rectangles
+        for sim in (fused, sweep):
+            sim.step(DT)                                  # new positions: nothing remembered
+            sim.set_option("profile", 1)
+            for _ in range(3):
+                sim.energy(); sim.moments(); sim.step(DT)
+        assert fused.info("sym_launches") == 3 * per_force * len(devices), fused.info("sym_launches")
+        assert sweep.info("sym_launches") == 3 * (per_force + per_sweep) * len(devices), sweep.info("sym_launches")
+        a, b = fused.state(), sweep.state()
+        for k in a:
+            assert np.array_equal(bits(a[k]), bits(b[k])), k          # the forces of a tracked evaluation are the plain ones
+        (k1, p1), (k2, p2) = fused.energy(), sweep.energy()
+        assert abs(p1 - p2) <= 5e-7 * abs(p2) and abs(k1 - k2) <= 1e-12 * abs(k2)
 
 
 def test_beyond_the_partial_plane_budget(gpu, O):
