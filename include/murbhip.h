@@ -233,8 +233,8 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  *                    block); 0 = the full square with the i side kept.  -1 (default) = the plan's own choice
  *   "sym_red"        variant 8: how the i-side sums of a group are folded over the wave: 0 = in registers (permlane
  *                    swaps + DPP), 1 = through LDS (fewer VALU instructions).  -1 (default) = the plan's own choice
- *   "sym_waves"      variant 8: waves per workgroup, 4 or 8; 0 = auto (8, with `split` 8, on one GPU below
- *                    45 000 bodies: a short launch drains faster; 4 otherwise)
+ *   "sym_waves"      variant 8: waves per workgroup, 4 or 8; 0 = auto (one GPU up to 27 blocks: 8 or 4 by a measured table per
+ *                    block count together with the item length, profiles/r03_small_plan_table.txt; 4 otherwise)
  *   "pad_aware"      variant 8: 1 (default) = the zero-mass padding slots that fill a slice up to whole blocks of 1024 are
  *                    not walked: the emptier block of a pair goes on the walked (i) side and its items end at its last
  *                    real body; 0 = every block as if full (kept for the A/B: -3 % at N = 30 000, -4 % for a rank of 8

@@ -236,7 +236,9 @@ constexpr int kNumVariants = 8;
 constexpr int kOneSidedVariant = 1;     // the persistent schedule (7) measured no faster: DESIGN.md §4.1
 constexpr int kPersistentVariant = 7;   // murb_force_persistent<8, 4, 4>
 constexpr int kSymmetricVariant = 8;    // murb_force_sym_kernel<4, 4 or 8>
-constexpr unsigned long kSymmetricMinBodies = 10240;   // below this the one-sided kernel wins (tools/sweep.py)
+constexpr unsigned long kSymmetricMinBodies = 2049;    // below this (one or two blocks) the one-sided kernel wins; round 2: 10 240 —
+                                                       // with items of 64-128 bodies the pair-symmetric kernel is 1.2-1.4x faster
+                                                       // from 3 blocks up (tools/small_plan_table.py: N = 3584 14.4 vs 20.5 us per step)
 constexpr int kRowsPerLaunch = kMaxParts / 2;
 
 int launch_persistent(const MurbForceArgs& a, const MurbSchedule& sc, hipStream_t s)
@@ -348,21 +350,33 @@ Plan make_plan(const murbhip_ctx* c)
         p.split = (c->jsplit == 1 || c->jsplit == 2 || c->jsplit == 4 || c->jsplit == 8 || c->jsplit == 16)
                       ? c->jsplit
                       : (items >= want ? 1 : (2 * items >= want ? 2 : (c->world == 1 || items >= 1000 ? 4 : (items >= 400 ? 8 : 16))));
-        // One GPU below 45 000 bodies (BASELINE's N = 30 000: 465 block pairs for 1024 workgroup slots): 8-wave
+        // Rounds 1-2, one GPU below 45 000 bodies (BASELINE's N = 30 000: 465 block pairs for 1024 workgroup slots): 8-wave
         // workgroups (2 per SIMD, 2 workgroups per CU: a CU's last workgroup still has two waves per SIMD to interleave),
         // quarter-block items with the last 30 % of the launch cut finer, diagonal blocks as triangular pieces.
         // tools/ab.py, interleaved, N = 30 000, wall per step: 8 waves / split 8 (round 1) 174.5 us, 8 / 4 / taper 30 /
         // triangular diagonal 170.5, 8 / 2 / taper 60 171.4; 4 waves never better.
-        const bool small = c->world == 1 && c->n < 45000;
-        p.waves = (c->sym_waves == 4 || c->sym_waves == 8) ? c->sym_waves : (small ? 8 : 4);
-        if (c->jsplit == 0 && c->sym_waves == 0 && small) p.split = 4;
+        // Round 3 (tools/small_plan_table.py: five plans interleaved for every block count T = 10 ... 44; padding-aware
+        // items, measurement without the profiling events): from T = 28 blocks up (N > 27 648) the plan of the larger
+        // problems — 4 waves, quarter blocks, 5 % taper, plain diagonal — is the fastest or within 1 % of it (N = 30 000:
+        // +3.6 % over the 8-wave plan, interleaved).  Below, the winner follows how the item count falls on the 1024
+        // (4 waves) or 512 (8 waves) workgroup slots of the chip, block count by block count, with up to 27 % between the
+        // plans at T = 10-16: a table (measured on the 256 CUs of an MI355X; any other CU count keeps the 8-wave plan).
+        struct SmallPlan { int waves, split, taper; bool diag_tri; };
+        static const SmallPlan kSmallPlans[5] = {{8, 4, 30, true}, {4, 4, 5, false}, {4, 8, 5, false}, {8, 8, 30, true}, {4, 16, 5, false}};
+        static const signed char kSmallPlanOfBlocks[25] = {4, 4, 4, 3, 3, 3, 4,                                      // T = 3 ... 9
+                                                           3, 3, 0, 2, 2, 1, 3, 0, 2, 1, 2, 0, 1, 2, 0, 1, 0, 2};   // T = 10 ... 27
+        const int T = (int)(c->slots / MURB_SYM_BLOCK);
+        const bool small = c->world == 1 && T <= 27;
+        const SmallPlan sp = kSmallPlans[(small && c->cu_count == 256 && T >= 3) ? kSmallPlanOfBlocks[T - 3] : (T < 10 ? 3 : 0)];
+        p.waves = (c->sym_waves == 4 || c->sym_waves == 8) ? c->sym_waves : (small ? sp.waves : 4);
+        if (c->jsplit == 0 && c->sym_waves == 0 && small) p.split = sp.split;
         while (p.split > 1 && MURB_SYM_BLOCK / p.split < 16 * p.waves) p.split /= 2;   // an item is at least one group per wave
         while (p.split > 1 && !fits(p.split)) p.split /= 2;   // the rows of the split actually used must fit, too
         // the tail of a launch in finer items (murb_schedule.h): +1.2-1.4 % on the force launch at N = 200 000 with 5 %,
         // nothing at 1M (the tail is 0.3 % of the launch there), and nothing on the wall clock of a rank of 8, whose three
         // short launches gain what their row sums lose to the extra rows
-        p.taper = c->taper >= 0 ? c->taper : (c->world > 1 ? 0 : (small ? 30 : (c->n <= 600000 ? 5 : 0)));
-        p.diag_tri = c->diag_tri >= 0 ? c->diag_tri != 0 : small;
+        p.taper = c->taper >= 0 ? c->taper : (c->world > 1 ? 0 : (small ? sp.taper : (c->n <= 600000 ? 5 : 0)));
+        p.diag_tri = c->diag_tri >= 0 ? c->diag_tri != 0 : (small && sp.diag_tri);
         // i-side sums through LDS: 599 instead of 616 VALU instructions per group; +0.8-1.3 % at N = 200 000, +1.7 % for
         // a rank of 8 (tools/ab.py)
         p.red = c->sym_red >= 0 ? c->sym_red : 1;
