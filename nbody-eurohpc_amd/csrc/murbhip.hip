@@ -165,6 +165,10 @@ struct murbhip_ctx {
     bool lf_half = false;     // leapfrog: device velocities lag the positions by half a step of lf_last_dt
     // acceleration cache: murbhip_compute_acc / a leapfrog read-out evaluated the forces at the CURRENT positions
     bool acc_current = false;        // acc_out holds them (a second evaluation would be bit-identical: skip it)
+    unsigned long state_serial = 1;  // counts the changes of the body state (upload, device initialisation, every update)
+    unsigned long metrics_serial = 0;// the state the cached metric sums below belong to (murbhip_energy and murbhip_moments of one
+    bool metrics_with_phi = false;   // tracked iteration share one pass of the metrics kernel and one read-back)
+    double metrics_sums[MURB_METRIC_VALUES] = {0};
     bool want_pe = false;            // the force launches being enqueued also sum the pair potential (murbhip_energy)
     bool pe_current = false;         // ... and the partial-row buffers hold it for the current positions
     float lf_last_dt = 0.f;
@@ -1039,6 +1043,7 @@ int enqueue_iteration(murbhip_ctx* c, float dt, int update_state)
     if (update_state) {
         if (exchanging) c->gather_pending = true;
         c->cur ^= 1;
+        ++c->state_serial;
     } else {
         c->acc_current = true;
         c->pe_current = c->want_pe && p.symmetric;
@@ -1397,6 +1402,7 @@ int murbhip_upload(murbhip_ctx* c, const float* qx, const float* qy, const float
     c->uploaded = true;
     c->lf_half = false;
     c->acc_current = false;
+    ++c->state_serial;
     return 0;
 }
 
@@ -1475,6 +1481,7 @@ int murbhip_init_bodies(murbhip_ctx* c, const char* scheme, unsigned long seed)
     c->uploaded = true;
     c->lf_half = false;
     c->acc_current = false;
+    ++c->state_serial;
     return 0;
 }
 
@@ -1644,6 +1651,7 @@ int murbhip_integrate_host_acc(murbhip_ctx* c, const float* ax, const float* ay,
     }
     c->cur ^= 1;
     c->acc_current = false;
+    ++c->state_serial;
     return 0;
 }
 
@@ -1660,6 +1668,11 @@ int ensure_acc_for_readout(murbhip_ctx* c)
 // in index order on the host).  want_phi: the potential sweep has just been written to phi_out.
 int device_metrics(murbhip_ctx* c, bool want_phi, double (&sums)[MURB_METRIC_VALUES])
 {
+    if (c->metrics_serial == c->state_serial && (c->metrics_with_phi || !want_phi)) {   // same state, sums already here
+        RC_TRY(murbhip_sync(c));
+        for (int k = 0; k < MURB_METRIC_VALUES; ++k) sums[k] = c->metrics_sums[k];
+        return 0;
+    }
     const unsigned blocks = (unsigned)((c->slice + 255) / 256);
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
@@ -1692,6 +1705,9 @@ int device_metrics(murbhip_ctx* c, bool want_phi, double (&sums)[MURB_METRIC_VAL
         for (unsigned b = 0; b < blocks; ++b)
             for (int k = 0; k < MURB_METRIC_VALUES; ++k) sums[k] += rows[(size_t)b * MURB_METRIC_VALUES + k];
     }
+    for (int k = 0; k < MURB_METRIC_VALUES; ++k) c->metrics_sums[k] = sums[k];
+    c->metrics_serial = c->state_serial;
+    c->metrics_with_phi = want_phi;
     return 0;
 }
 }  // namespace
