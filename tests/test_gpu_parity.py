@@ -736,6 +736,7 @@ def test_bench_contract(gpu):
     assert abs(e["value"] - 1e12 * e["steps"] / (e["ms_per_step"] * e["steps"] * 1e-3)) / e["value"] < 1e-6 and e["value"] > 3e12
     assert 0.5 < e["roofline"]["frac"] < 1.0 and e["roofline"]["kernel_ms_avg"] <= e["ms_per_step"] and e["plan"]["kernel_variant"] == 8
     assert e["wall_s_incl_setup"] < 15
+    assert e["parity"]["max_rel"] <= e["parity"]["tolerance_max_rel"] and "N=1000000" in e["parity"]["vs"]   # fp64 spot check at that size too
     # the workload string names the size that ran and the BASELINE.json config it is
     assert "N=30000" in d["config"]["workload"] and "configs[1]" in d["config"]["workload"]
     # peak from the device's properties; algorithmic vs executed flops kept apart
