@@ -1,0 +1,89 @@
+"""Lab: randomized differential run of the C ABI — random sizes, shard counts and plan options against the fp64 oracle
+(accelerations) and against a plain single-GPU run (two steps, potential energy).  Not part of the test suite (minutes of GPU
+time); a net for rare layout / plan combinations the parametrized tests do not list.
+    python tools/fuzz_plans.py [--cases 120] [--seed 1]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nbody-eurohpc_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import murbhip  # noqa: E402
+import oracle as O  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=120)
+ap.add_argument("--seed", type=int, default=1)
+args = ap.parse_args()
+rng = np.random.default_rng(args.seed)
+SOFT, DT = np.float32(2e8), 3600.0
+bad = 0
+t_start = time.time()
+for case in range(args.cases):
+    n = int(rng.choice([rng.integers(1, 3000), rng.integers(3000, 20000), rng.integers(20000, 70000)]))
+    shards = int(rng.choice([1, 1, 2, 3, 4, 5, 8]))
+    shards = min(shards, n)
+    scheme = "galaxy" if rng.random() < 0.7 else "random"
+    opts = {"variant": int(rng.choice([0, 0, 8, 1]))}
+    if rng.random() < 0.5:
+        opts["jsplit"] = int(rng.choice([1, 2, 4, 8, 16]))
+    if rng.random() < 0.4:
+        opts["sym_waves"] = int(rng.choice([4, 8]))
+    if rng.random() < 0.4:
+        opts["taper"] = int(rng.choice([0, 5, 30, 60, 100]))
+    if rng.random() < 0.4:
+        opts["diag_tri"] = int(rng.integers(0, 2))
+    if rng.random() < 0.3:
+        opts["tri_div"] = int(rng.choice([1, 2, 4, 8]))
+    if rng.random() < 0.2:
+        opts["pad_aware"] = 0
+    if rng.random() < 0.3:
+        opts["overlap"] = int(rng.integers(0, 3))
+    if rng.random() < 0.3:
+        opts["tri_first_pct"] = int(rng.choice([0, 25, 50, 75, 100]))
+    if rng.random() < 0.2:
+        opts["sym_red"] = int(rng.integers(0, 2))
+    if rng.random() < 0.15:
+        opts["xcd_order"] = 1
+    if rng.random() < 0.15:
+        opts["sym_pass_mb"] = int(rng.choice([1, 2, 8]))
+    leap = rng.random() < 0.2
+    if opts["variant"] == 1:      # the one-sided kernel takes 0 (auto) or a chunk count up to 32 for "jsplit"
+        opts.pop("jsplit", None)
+    s = O.init_bodies(n, scheme)
+    idx = np.arange(n) if n <= 6000 else rng.choice(n, 4096, replace=False)
+    truth = O.accel_f64_subset(s, idx, SOFT)
+    try:
+        kw = {"devices": [0] * shards} if shards > 1 else {}
+        with murbhip.Simulation(n, soft=SOFT) as ref, murbhip.Simulation(n, soft=SOFT, **kw) as sim:
+            for k, v in opts.items():
+                sim.set_option(k, v)
+            for x in (ref, sim):
+                x.set_option("integrator", int(leap))
+                x.upload(s)
+            sim.compute_acc(); sim.sync()
+            acc = sim.acc()
+            err = float(O.rel_err([c[idx] for c in acc], truth).max())
+            pe_s = sim.energy()[1]; pe_r = ref.energy()[1]
+            sim.steps(DT, 2); ref.steps(DT, 2)
+            a, b = sim.state(), ref.state()
+            scale = max(float(np.abs(b[k]).max()) for k in ("qx", "qy", "qz")) or 1.0
+            dpos = max(float(np.abs(a[k] - b[k]).max()) for k in ("qx", "qy", "qz")) / scale
+            used = int(sim.info("variant"))
+        tol = 2e-6 if scheme == "galaxy" else 4e-6
+        # the potential: with a few hundred bodies the galaxy's central body (10^4 times the others) makes its own term, which
+        # every evaluation carries in fp32 and takes out again, as large as all pair terms together: 1e-5 there, 2e-6 from 2000 up
+        pe_tol = 2e-6 if n >= 2000 else 2e-5
+        ok = err <= tol and dpos <= 2e-6 and abs(pe_s - pe_r) <= pe_tol * abs(pe_r) + 1e-30
+    except Exception as e:   # noqa: BLE001
+        ok, err, dpos, used = False, float("nan"), float("nan"), -1
+        print("   exception:", e)
+    bad += not ok
+    print(f"case {case:3d} {'ok ' if ok else 'BAD'} n={n} shards={shards} {scheme} leap={int(leap)} used variant {used} opts={opts} acc err {err:.2e} pos diff {dpos:.2e} "
+          f"[{time.time() - t_start:.0f} s]", flush=True)
+print(f"{args.cases - bad} of {args.cases} cases ok")
+sys.exit(1 if bad else 0)
