@@ -898,7 +898,9 @@ int shard_iteration_sym_multi(murbhip_ctx* c, Shard& sh, const Plan& p, float dt
         RC_TRY(wait_send_buffer_free(c, sh));
         RC_TRY(enqueue_sym_rowsum(sh.sym_main, sh.sym_send, (unsigned int)c->slice, sh.compute));
         HIP_TRY(hipEventRecord(sh.ev_rowsum, sh.compute));
-        note_interactions(c, sh, (double)sh.count * (double)c->n);
+        // what ONE launch covers on average: the rank's share of the step over its non-empty force launches
+        const int launches = (t1 > 0) + (own - t1 > 0 || c->overlap == 2) + (sh.sym_items_total - own > 0);
+        note_interactions(c, sh, (double)sh.count * (double)c->n / (double)std::max(launches, 1));
         return 0;
     }();
     if (copies) c->crew->meet();   // every shard's ev_rowsum is recorded

@@ -803,6 +803,8 @@ def test_bench_under_torchrun_one_rank(gpu):
     f = ex["force_ms_avg"]
     assert f["triangle_part_1"] > 0 and f["triangle_part_2"] > 0 and f["rectangles"] == 0
     assert "one_sided_plan" not in d                       # needs more than one rank
+    roof = d["roofline"]                                   # two launches per step share the step's N^2 interactions
+    assert abs(roof["launches_per_step"] - 2) < 1e-9 and abs(roof["interactions_per_launch"] - 30000.0 ** 2 / 2) < 1 and 0.3 < roof["frac"] < 1.0
     assert d["other_configs"][0]["n_bodies"] == 1000000 and d["other_configs"][0]["plan"]["kernel_variant"] == 8
 
 
