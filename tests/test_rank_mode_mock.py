@@ -194,6 +194,9 @@ def test_bench_py_with_several_ranks(gpu, world, n):
     assert alt["ms_per_step"] > 0 and abs(alt["half_ring_speedup"] - alt["ms_per_step"] / d["ms_per_step"]) < 1e-9
     p2p = d["p2p_plan"]                # both exchanges as grouped sends / receives, timed beside the collectives
     assert p2p["ms_per_step"] > 0 and abs(p2p["speedup_over_collectives"] - p2p["collectives_ms_per_step_same_context"] / p2p["ms_per_step"]) < 1e-9
+    one = d["one_process_plan"]         # the drop-in form: rank 0 alone drives all shards from one process, both exchanges
+    for ex in ("copy", "rccl"):
+        assert one[ex]["ms_per_step"] > 0 and one[ex]["ms_per_step_sync_each_iteration"] > 0 and one[ex]["kernel_variant"] == 8, one
     oc = {e["n_bodies"]: e for e in d["other_configs"]}
     assert set(oc) == {30000, 60000}
     for e in oc.values():
