@@ -248,6 +248,24 @@ def test_bench_py_watchdog_reports_a_stuck_phase(gpu):
     assert d["environment"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and d["environment"]["MURBHIP_RCCL_LIBRARY"] == MOCK
 
 
+def test_bench_py_keeps_the_measurement_when_an_extra_fails(gpu):
+    """N > 1: a failure AFTER the main measurement (here injected into the first of the other sizes) must not cost the
+    measurement: rank 0 prints the line it has, with the failure under "incomplete", and the run exits 0."""
+    import json
+    env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK, MURB_BENCH_BACKEND="gloo", MURB_BENCH_SHARE_GPU="1", MURB_BENCH_UNTIMED_SCALE="0.1",
+               MURB_BENCH_OTHER_CONFIGS="30000:10", MURB_BENCH_FAIL_IN="other config")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bodies", "40000", "--steps", "6", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, (r.stdout, r.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["n_gpus"] == 2 and d["rank_mode_check"]["positions_identical_on_all_ranks"] and "exchange" in d
+    assert "injected failure" in d["incomplete"]["error"] and d["incomplete"]["phase"].startswith("other config")
+    assert r.returncode == 0, r.stderr[-1500:]
+
+
 def test_bench_py_reports_a_failed_start(gpu):
     """N > 1 with a collective library that cannot be loaded: the run must end at once with ONE JSON line from rank 0 whose
     "error" carries the library's message and the phase, and a non-zero exit code."""
