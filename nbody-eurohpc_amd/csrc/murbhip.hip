@@ -833,10 +833,18 @@ int shard_reduce_scatter(murbhip_ctx* c, Shard& sh)
         RC_TRY(nccl_rc(rccl().ReduceScatter(sh.sym_send, sh.sym_recv, chunk_floats, kRcclFloat, kRcclSum, sh.comm_rccl, sh.comm)));
     } else {
         if (idle) return 0;
+        // Under the half-ring schedule only the floor(W/2) ranks BEHIND this one (and the rank itself) hold contributions to its
+        // slice: the chunks the others keep for it are zero and are not read (no xGMI traffic for zeros).  Fixed order: own,
+        // then by distance along the ring.
+        const int W = c->world, D = W / 2;
         MurbPeerPtrs peers{};
-        peers.n = (int)c->shards.size();
-        for (size_t k = 0; k < c->shards.size(); ++k) peers.p[c->shards[k].rank] = c->shards[k].sym_send;
-        for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.comm, peer.ev_rowsum, 0));
+        peers.n = 0;
+        for (int d = 0; d <= D; ++d) {
+            const int from = (sh.rank - d + W) % W;
+            if (d > 0 && from == sh.rank) break;
+            for (Shard& peer : c->shards)
+                if (peer.rank == from) { peers.p[peers.n++] = peer.sym_send; HIP_TRY(hipStreamWaitEvent(sh.comm, peer.ev_rowsum, 0)); }
+        }
         span = span_begin(c, sh, kProfReduceScatter, sh.comm, &rc);
         RC_TRY(rc);
         hipLaunchKernelGGL(murb_sym_peer_sum_kernel, dim3((chunk_floats + 255) / 256), dim3(256), 0, sh.comm, peers,
@@ -853,8 +861,11 @@ int shard_reduce_scatter(murbhip_ctx* c, Shard& sh)
 int wait_send_buffer_free(murbhip_ctx* c, Shard& sh)
 {
     if (!c->reduce_pending) return 0;
-    if (c->exchange == 0) { for (Shard& peer : c->shards) HIP_TRY(hipStreamWaitEvent(sh.compute, peer.ev_reduced, 0)); }
-    else HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
+    if (c->exchange == 0) {   // the readers of this shard's send buffer: itself and the floor(W/2) ranks AHEAD of it (shard_reduce_scatter)
+        const int W = c->world, D = W / 2;
+        for (Shard& peer : c->shards)
+            if ((peer.rank - sh.rank + W) % W <= D) HIP_TRY(hipStreamWaitEvent(sh.compute, peer.ev_reduced, 0));
+    } else HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_reduced, 0));
     return 0;
 }
 
