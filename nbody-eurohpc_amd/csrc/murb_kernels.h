@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void murb_integrate_kernel(const MurbIntegrate
 // removed, .cu:287-294) ; m v ; m q x v ; m q ; m.  One block = 256 consecutive slots of the rank's slice;
 // the 12 block sums are written in a fixed order (wave shuffle tree, then the 4 waves through LDS) and the
 // host adds the few hundred block rows in index order: bit-reproducible.
-#define MURB_METRIC_VALUES 13
+#define MURB_METRIC_VALUES 12
 struct MurbMetricsArgs {
     const float4* rec;      // positions + G*m, all slots
     const float4* vel;      // local slice
@@ -538,7 +538,6 @@ __global__ __launch_bounds__(256) void murb_metrics_kernel(const MurbMetricsArgs
         v[5] = m * (y * wz - z * wy); v[6] = m * (z * wx - x * wz); v[7] = m * (x * wy - y * wx);
         v[8] = m * x; v[9] = m * y; v[10] = m * z;
         v[11] = m;
-        v[12] = m * m;   // for the self terms of the fused pair potential (murbhip_energy)
     }
 #pragma unroll
     for (int k = 0; k < MURB_METRIC_VALUES; ++k)

@@ -127,14 +127,15 @@ __device__ __forceinline__ void murb_interact_sym(const murb_f2 xj, const murb_f
 
 // force + pair potential (PHI = 2): the same operations in the same order as murb_interact_sym (the forces of a tracked
 // evaluation are bit-identical to an untracked one) plus G m_i G m_j / r of the pair summed per lane: two more packed
-// instructions (three in the triangular form of a diagonal item, which keeps the masked and the unmasked sum apart: the
-// pairs of a piece's own step are met from both sides, with only the i side applied).  What the tracked metrics need is the
-// TOTAL potential energy, not a potential per body: one float per group of 4 i bodies instead of a second N^2 sweep.
-template <int DYN>
+// instructions.  What the tracked metrics need is the TOTAL potential energy, not a potential per body: one float per group
+// of 4 i bodies instead of a second N^2 sweep.  Items on the DIAGONAL (i block = j block) do not count here: they meet pairs
+// from both sides and every body itself, and that self term — (G m)^2 / soft, for the galaxy's central body 10^4 times
+// everything around it — would swallow the low bits of its neighbours in an fp32 chain; murb_sym_pe_diag_kernel sums the
+// diagonal blocks' pairs separately, in fp64 and without the self terms.
 __device__ __forceinline__ void murb_interact_sym_pe(const murb_f2 xj, const murb_f2 yj, const murb_f2 zj, const murb_f2 gj,
-                                                     const float xi, const float yi, const float zi, const float gi, const float gi_raw,
+                                                     const float xi, const float yi, const float zi, const float gi, const float gi_pe,
                                                      const float soft2, murb_f2& aix, murb_f2& aiy, murb_f2& aiz,
-                                                     murb_f2& ajx, murb_f2& ajy, murb_f2& ajz, murb_f2& pe_both, murb_f2& pe_all)
+                                                     murb_f2& ajx, murb_f2& ajy, murb_f2& ajz, murb_f2& pe)
 {
     const murb_f2 dx = xj - xi;
     const murb_f2 dy = yj - yi;
@@ -149,8 +150,7 @@ __device__ __forceinline__ void murb_interact_sym_pe(const murb_f2 xj, const mur
     const murb_f2 fi = gj * inv3;          // pull of j on i
     const murb_f2 fj = inv3 * (-gi);       // pull of i on j (opposite direction)
     const murb_f2 gg = gj * inv;           // G m_j / r
-    pe_both = __builtin_elementwise_fma(gg, (murb_f2)(gi), pe_both);
-    if (DYN) pe_all = __builtin_elementwise_fma(gg, (murb_f2)(gi_raw), pe_all);
+    pe = __builtin_elementwise_fma(gg, (murb_f2)(gi_pe), pe);
     aix = __builtin_elementwise_fma(fi, dx, aix);
     aiy = __builtin_elementwise_fma(fi, dy, aiy);
     aiz = __builtin_elementwise_fma(fi, dz, aiz);
@@ -260,7 +260,7 @@ __device__ __forceinline__ void murb_sym_walk(const MurbSymArgs& a, const float4
         murb_f2 aix[R], aiy[R], aiz[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { aix[r] = (murb_f2)(0.f); aiy[r] = (murb_f2)(0.f); aiz[r] = (murb_f2)(0.f); }
-        murb_f2 pe_both = (murb_f2)(0.f), pe_all = (murb_f2)(0.f);   // PHI = 2: this group's pair potential (chains of 32 terms)
+        murb_f2 pe = (murb_f2)(0.f);   // PHI = 2: this group's pair potential (chains of 32 terms)
 
 #pragma unroll
         for (int p = 0; p < MURB_SYM_STEPS; ++p) {
@@ -276,8 +276,8 @@ __device__ __forceinline__ void murb_sym_walk(const MurbSymArgs& a, const float4
                     if constexpr (PHI == 1)
                         murb_interact_sym_phi(xj, yj, zj, gj, xi[r], yi[r], zi[r], gie, soft2, aix[r], ajx[p]);
                     else if constexpr (PHI == 2)
-                        murb_interact_sym_pe<DYN>(xj, yj, zj, gj, xi[r], yi[r], zi[r], gie, gi[r], soft2, aix[r], aiy[r], aiz[r], ajx[p],
-                                                  ajy[p], ajz[p], pe_both, pe_all);
+                        murb_interact_sym_pe(xj, yj, zj, gj, xi[r], yi[r], zi[r], gie, gi[r], soft2, aix[r], aiy[r], aiz[r], ajx[p],
+                                             ajy[p], ajz[p], pe);
                     else
                         murb_interact_sym(xj, yj, zj, gj, xi[r], yi[r], zi[r], gie, soft2, aix[r], aiy[r], aiz[r], ajx[p], ajy[p],
                                           ajz[p]);
@@ -302,16 +302,7 @@ __device__ __forceinline__ void murb_sym_walk(const MurbSymArgs& a, const float4
         } else {
 #pragma unroll
             for (int k = 0; k < 12; ++k) stage[k * 80 + stage_wr] = v[k];
-            if constexpr (PHI == 2) {
-                // off the diagonal every pair is met once.  A diagonal item in its plain form meets every ordered pair of the
-                // block (and every body itself): half of it (pe_scale).  In its triangular form: the later steps once
-                // (pe_both), the own step from both sides (pe_all - pe_both): half of that.  The self terms (G m_i)^2 / soft
-                // the halves still contain are taken out on the host.
-                float pg = pe_both.x + pe_both.y;
-                if (DYN) pg = 0.5f * (pg + (pe_all.x + pe_all.y));
-                else pg *= pe_scale;
-                stage[12 * 80 + stage_wr] = pg;
-            }
+            if constexpr (PHI == 2) stage[12 * 80 + stage_wr] = (pe.x + pe.y) * pe_scale;   // pe_scale = 0 on the diagonal
             team_sum(g);
         }
     }
@@ -395,10 +386,10 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void murb_force_sym_kernel(const 
     float* const stage = reinterpret_cast<float*>(&scratch[0][0][0]) + wave * ((PHI == 2 ? 13 : 12) * 80);
     if (triangular)
         murb_sym_walk<WAVES, ILOAD, PHI, RED, 1>(a, tileA, tileB, stage, lane, wave, groups_per_wave, (unsigned int)i_item_slot, out_off,
-                                                 out_stride, 1.f, p_first, p_sym, ajx, ajy, ajz);
+                                                 out_stride, 0.f, p_first, p_sym, ajx, ajy, ajz);
     else
         murb_sym_walk<WAVES, ILOAD, PHI, RED, 0>(a, tileA, tileB, stage, lane, wave, groups_per_wave, (unsigned int)i_item_slot, out_off,
-                                                 out_stride, no_j_side ? 0.5f : 1.f, 0, 0, ajx, ajy, ajz);
+                                                 out_stride, (i_item_slot / MURB_SYM_BLOCK == J) ? 0.f : 1.f, 0, 0, ajx, ajy, ajz);
 
     // j side: fold the waves pairwise in a fixed order (WAVES = 4: 3+2 -> 1+0 -> 0), wave 0 writes the item's j row
     if (!no_j_side) {
@@ -569,6 +560,44 @@ __global__ __launch_bounds__(MURB_ROWSUM_THREADS) void murb_sym_rowsum_integrate
     float* wa = reinterpret_cast<float*>(a.vel + va);
     float* wb = reinterpret_cast<float*>(a.vel + va + MURB_TILE_PAIRS);
     wa[h] = vx; wa[2 + h] = vy; wb[h] = vz;
+}
+
+// The pair potential of the DIAGONAL blocks: sum over the unordered pairs {i, j}, i != j, of a block's bodies of
+// G m_i G m_j / sqrt(r^2 + soft^2) — in fp64 from the first addition on (the diagonal is 1/T of the work: N x 512 pair terms).
+// Every pair once: body i meets the 512 bodies that follow it round the block, j = i + 1 ... i + 512 (mod 1024); the pair
+// {i, i + 512} is met from both ends and counts half.  16 workgroups of 256 threads per block (one would leave a small
+// problem on T of the 256 CUs for 100 us): workgroup y takes the bodies 64 y ... 64 y + 63, its wave w the offsets
+// 128 w + 1 ... 128 w + 128.  out[16 * block + y]; the host adds them in index order.
+#define MURB_PE_DIAG_SPLIT 16
+__global__ __launch_bounds__(256) void murb_sym_pe_diag_kernel(const float4* rec, int first_block, float soft2, double* out)
+{
+    __shared__ float4 body[MURB_SYM_BLOCK];   // x, y, z, G m
+    __shared__ double red[4];
+    const int t = threadIdx.x, block = first_block + blockIdx.x / MURB_PE_DIAG_SPLIT, y = blockIdx.x % MURB_PE_DIAG_SPLIT;
+    for (int k = t; k < MURB_SYM_BLOCK; k += 256) {
+        const unsigned long slot = (unsigned long)block * MURB_SYM_BLOCK + k;
+        const unsigned long ra = murb_rec_a(slot >> 1);
+        const float4 A = rec[ra], B = rec[ra + MURB_TILE_PAIRS];
+        body[k] = (k & 1) ? make_float4(A.y, A.w, B.y, B.w) : make_float4(A.x, A.z, B.x, B.z);
+    }
+    __syncthreads();
+    const int i = 64 * y + (t & 63), wave = t >> 6;
+    const float4 me = body[i];
+    double acc = 0.0;
+#pragma unroll 4
+    for (int off = 128 * wave + 1; off <= 128 * wave + 128; ++off) {
+        const float4 o = body[(i + off) & (MURB_SYM_BLOCK - 1)];
+        const float dx = o.x - me.x, dy = o.y - me.y, dz = o.z - me.z;
+        const float inv = __builtin_amdgcn_rsqf(fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, soft2))));
+        const float term = o.w * inv;
+        acc += (double)(off == MURB_SYM_BLOCK / 2 ? 0.5f * term : term);
+    }
+    acc *= (double)me.w;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((t & 63) == 0) red[wave] = acc;
+    __syncthreads();
+    if (t == 0) out[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
 // Sum of the groups' pair potentials of a set of launches (PHI = 2: `count` floats behind the three components of the partial

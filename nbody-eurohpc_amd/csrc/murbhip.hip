@@ -70,7 +70,6 @@ struct SymSet {
     float* part = nullptr;
     size_t comp_stride = 0;           // floats per component (single pass)
     MurbSymBlockRows* rows = nullptr; // device copy of the table
-    double* pe_sums = nullptr;        // murbhip_energy: the workgroups' partial sums of the set's pair potentials [kPeSumBlocks]
     int nblocks = 0;                  // entries (all passes)
     std::vector<SymPass> passes;      // more than one entry: multi-pass evaluation
 };
@@ -89,7 +88,7 @@ struct Shard {
     float* phi_out = nullptr;    // murbhip_energy's potential sweep (same shape as acc_out), allocated on first use
     float* mass = nullptr;       // masses of the local slice as uploaded (metrics)
     float* radius = nullptr;     // radii of the local slice: only after murbhip_init_bodies (the host never sent them)
-    double* metrics = nullptr;   // block sums of murb_metrics_kernel
+    double* metrics = nullptr;   // block sums of murb_metrics_kernel, then murbhip_energy's pair potentials (metrics_doubles)
     // pair-symmetric kernel: item table and partial-row layouts (built by build_sym_schedule for one plan)
     MurbSymItem* sym_items = nullptr;
     int sym_items_own = 0, sym_items_total = 0;   // [0, own) = own-slice triangle, the rest need the gathered positions
@@ -634,7 +633,7 @@ int ensure_accp(murbhip_ctx* c, Shard& sh)
 
 void free_sym_set(SymSet& st)
 {
-    hipFree(st.part); hipFree(st.rows); hipFree(st.pe_sums);
+    hipFree(st.part); hipFree(st.rows);
     st = SymSet{};
 }
 
@@ -647,7 +646,6 @@ int upload_sym_set(Shard& sh, SymSet& st, const std::vector<MurbSymBlockRows>& t
     // (murb_kernels_sym.h, PHI = 2: entry ioff / 4 + group; zero wherever no item has groups)
     const size_t bytes = (3 * floats + floats / MURB_SYM_R + 1) * sizeof(float);
     HIP_TRY(hipMalloc((void**)&st.part, bytes));
-    HIP_TRY(hipMalloc((void**)&st.pe_sums, kPeSumBlocks * sizeof(double)));
     HIP_TRY(hipMemsetAsync(st.part, 0, bytes, sh.compute));   // every cell has a writer; zero anyway (on OUR stream: non-blocking w.r.t. stream 0)
     HIP_TRY(hipMalloc((void**)&st.rows, table.size() * sizeof(MurbSymBlockRows)));
     HIP_TRY(hipMemcpy(st.rows, table.data(), table.size() * sizeof(MurbSymBlockRows), hipMemcpyHostToDevice));
@@ -1677,21 +1675,41 @@ int ensure_acc_for_readout(murbhip_ctx* c)
     return 0;
 }
 
-// The O(N) sums of the tracked metrics over this process's bodies (murb_metrics_kernel + the block rows added
-// in index order on the host).  want_phi: the potential sweep has just been written to phi_out.
-int device_metrics(murbhip_ctx* c, bool want_phi, double (&sums)[MURB_METRIC_VALUES])
+// What a shard's read-out buffer (Shard::metrics) holds, in doubles: the block rows of murb_metrics_kernel, then the pair
+// potentials of murbhip_energy — the partial sums of the two sets' groups (murb_sym_pe_sum_kernel) and the own slice's
+// diagonal blocks (murb_sym_pe_diag_kernel).  One buffer so that one copy brings a tracked iteration's numbers to the host.
+struct MetricsLayout {
+    size_t blocks, rows, pe_main, pe_tri, pe_diag, own_blocks, total;
+};
+MetricsLayout metrics_layout(const murbhip_ctx* c)
 {
-    if (c->metrics_serial == c->state_serial && (c->metrics_with_phi || !want_phi)) {   // same state, sums already here
+    MetricsLayout l{};
+    l.blocks = (c->slice + 255) / 256;
+    l.rows = 0;
+    l.pe_main = l.blocks * MURB_METRIC_VALUES;
+    l.pe_tri = l.pe_main + kPeSumBlocks;
+    l.pe_diag = l.pe_tri + kPeSumBlocks;
+    l.own_blocks = c->slice / MURB_SYM_BLOCK;
+    l.total = l.pe_diag + l.own_blocks * MURB_PE_DIAG_SPLIT;
+    return l;
+}
+
+// The O(N) sums of the tracked metrics over this process's bodies (murb_metrics_kernel + the block rows added
+// in index order on the host).  want_phi: the potential sweep has just been written to phi_out.  pair_sum: also add up
+// the pair potentials murbhip_energy has just enqueued into the buffers' tails (then the kept sums are not enough).
+int device_metrics(murbhip_ctx* c, bool want_phi, double (&sums)[MURB_METRIC_VALUES], double* pair_sum = nullptr)
+{
+    if (!pair_sum && c->metrics_serial == c->state_serial && (c->metrics_with_phi || !want_phi)) {   // same state, sums already here
         RC_TRY(murbhip_sync(c));
         for (int k = 0; k < MURB_METRIC_VALUES; ++k) sums[k] = c->metrics_sums[k];
         return 0;
     }
-    const unsigned blocks = (unsigned)((c->slice + 255) / 256);
+    const MetricsLayout l = metrics_layout(c);
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
         if (!sh.metrics) {
-            HIP_TRY(hipMalloc((void**)&sh.metrics, (size_t)blocks * MURB_METRIC_VALUES * sizeof(double)));
-            sh.bytes += (size_t)blocks * MURB_METRIC_VALUES * sizeof(double);
+            HIP_TRY(hipMalloc((void**)&sh.metrics, l.total * sizeof(double)));
+            sh.bytes += l.total * sizeof(double);
         }
         if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
         MurbMetricsArgs a{};
@@ -1706,17 +1724,22 @@ int device_metrics(murbhip_ctx* c, bool want_phi, double (&sums)[MURB_METRIC_VAL
         a.acc_stride = (unsigned int)c->slice;
         a.half_dt = c->lf_half ? 0.5f * c->lf_last_dt : 0.f;
         a.g_over_soft = (double)c->g / std::sqrt((double)c->soft2);
-        hipLaunchKernelGGL(murb_metrics_kernel, dim3(blocks), dim3(256), 0, sh.compute, a);
+        hipLaunchKernelGGL(murb_metrics_kernel, dim3((unsigned)l.blocks), dim3(256), 0, sh.compute, a);
         RC_TRY(hip_rc(hipGetLastError()));
     }
     RC_TRY(murbhip_sync(c));
     for (double& v : sums) v = 0.0;
-    std::vector<double> rows((size_t)blocks * MURB_METRIC_VALUES);
+    if (pair_sum) *pair_sum = 0.0;
+    std::vector<double> host(pair_sum ? l.total : l.pe_main);
     for (Shard& sh : c->shards) {
         HIP_TRY(hipSetDevice(sh.device));
-        HIP_TRY(hipMemcpy(rows.data(), sh.metrics, rows.size() * sizeof(double), hipMemcpyDeviceToHost));
-        for (unsigned b = 0; b < blocks; ++b)
-            for (int k = 0; k < MURB_METRIC_VALUES; ++k) sums[k] += rows[(size_t)b * MURB_METRIC_VALUES + k];
+        HIP_TRY(hipMemcpy(host.data(), sh.metrics, host.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < l.blocks; ++b)
+            for (int k = 0; k < MURB_METRIC_VALUES; ++k) sums[k] += host[b * MURB_METRIC_VALUES + k];
+        if (!pair_sum) continue;
+        if (sh.sym_main.part) for (int k = 0; k < kPeSumBlocks; ++k) *pair_sum += host[l.pe_main + k];
+        if (sh.sym_tri.part) for (int k = 0; k < kPeSumBlocks; ++k) *pair_sum += host[l.pe_tri + k];
+        for (size_t b = 0; b < l.own_blocks * MURB_PE_DIAG_SPLIT; ++b) *pair_sum += host[l.pe_diag + b];
     }
     for (int k = 0; k < MURB_METRIC_VALUES; ++k) c->metrics_sums[k] = sums[k];
     c->metrics_serial = c->state_serial;
@@ -1737,8 +1760,8 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
         // packed instructions per 18 sum G m_i G m_j / r of every pair a wave meets, one float per group of 4 i bodies behind
         // the partial rows) — no second N^2 sweep.  The forces of that evaluation are remembered, so a step that follows only
         // launches the state update (also with several shards): a tracked iteration costs one force evaluation.  Every shard
-        // sums the pairs IT evaluated; a body's self term (G m_i)^2 / soft, half of which the diagonal items leave in, goes
-        // out with the shard's own bodies.  (Several passes over one shared buffer, N > 2.4 M: the separate sweep below.)
+        // sums the pairs IT evaluated off the diagonal, plus the pairs inside its own blocks (murb_sym_pe_diag_kernel: fp64,
+        // no self terms).  (Several passes over one shared buffer, N > 2.4 M: the separate sweep below.)
         if (!(c->acc_current && c->pe_current)) {
             c->acc_current = false;   // forces alone are not enough: evaluate again, this time with the pair potential
             c->want_pe = true;
@@ -1749,29 +1772,32 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
         bool still_one_pass = true;   // the evaluation above may have built the tables for the first time
         for (const Shard& sh : c->shards) still_one_pass = still_one_pass && sh.sym_main.passes.size() <= 1;
         if (still_one_pass) {
+            const MetricsLayout l = metrics_layout(c);
             for (Shard& sh : c->shards) {
                 HIP_TRY(hipSetDevice(sh.device));
+                if (!sh.metrics) {
+                    HIP_TRY(hipMalloc((void**)&sh.metrics, l.total * sizeof(double)));
+                    sh.bytes += l.total * sizeof(double);
+                }
+                const size_t at[2] = {l.pe_main, l.pe_tri};
+                int k = 0;
                 for (SymSet* st : {&sh.sym_main, &sh.sym_tri}) {
+                    const size_t off = at[k++];
                     if (!st->part) continue;
                     hipLaunchKernelGGL(murb_sym_pe_sum_kernel, dim3(kPeSumBlocks), dim3(1024), 0, sh.compute, st->part + 3 * st->comp_stride,
-                                       (unsigned long)(st->comp_stride / MURB_SYM_R + 1), st->pe_sums);
+                                       (unsigned long)(st->comp_stride / MURB_SYM_R + 1), sh.metrics + off);
                     RC_TRY(hip_rc(hipGetLastError()));
                 }
+                // the diagonal blocks (the own slice's) separately, in fp64 and without the bodies' own terms
+                hipLaunchKernelGGL(murb_sym_pe_diag_kernel, dim3((unsigned)(l.own_blocks * MURB_PE_DIAG_SPLIT)), dim3(256), 0, sh.compute, sh.rec[c->cur],
+                                   (int)(sh.rank * l.own_blocks), c->soft2, sh.metrics + l.pe_diag);
+                RC_TRY(hip_rc(hipGetLastError()));
             }
-            double sums[MURB_METRIC_VALUES];
-            RC_TRY(device_metrics(c, false, sums));   // syncs
-            double pair_sum = 0.0, part[kPeSumBlocks];
-            for (Shard& sh : c->shards) {
-                HIP_TRY(hipSetDevice(sh.device));
-                for (SymSet* st : {&sh.sym_main, &sh.sym_tri}) {
-                    if (!st->part) continue;
-                    HIP_TRY(hipMemcpy(part, st->pe_sums, sizeof part, hipMemcpyDeviceToHost));
-                    for (double v : part) pair_sum += v;
-                }
-            }
+            double sums[MURB_METRIC_VALUES], pair_sum = 0.0;
+            RC_TRY(device_metrics(c, false, sums, &pair_sum));   // syncs; one copy per shard
             const double g = (double)c->g;
             *kinetic = sums[0];
-            *potential = -pair_sum / g + 0.5 * g / std::sqrt((double)c->soft2) * sums[12];
+            *potential = -pair_sum / g;
             return 0;
         }
         c->pe_current = false;   // several passes after all: fall through to the sweep (the forces stay remembered)
