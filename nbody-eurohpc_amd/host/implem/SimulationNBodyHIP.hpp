@@ -18,12 +18,14 @@ template <typename T> class SimulationNBodyHIP : public SimulationNBodyInterface
 
   public:
     // `devices`: HIP ordinals to spread the bodies over ({0} = one GPU).  Needs a HIPBodiesAllocator.
+    // Construction ends with an untimed device warm-up (warmUp below; MURBHIP_WARMUP_MS in the environment, default 50, 0 = none).
     SimulationNBodyHIP(const BodiesAllocatorInterface<T> &allocator, const T soft = 0.035f,
                        const std::vector<int> &devices = {0}, int exchange = 1);
     virtual ~SimulationNBodyHIP() = default;
 
     void computeOneIteration() override;   // enqueue only; the driver syncs (main.cpp:356-368)
     void synchronize();                    // that sync, for callers without HIP headers
+    void warmUp(double milliseconds);      // force evaluations on the current state for about that long (state unchanged)
     const accSoA_t<T> &getAccSoA();        // accelerations of the last iteration (test hook)
 };
 

@@ -62,6 +62,7 @@ def lib():
         L.murbhip_download_state.argtypes = [C.c_void_p] + [_fp] * 6
         L.murbhip_download_acc.argtypes = [C.c_void_p] + [_fp] * 3
         L.murbhip_compute_acc.argtypes = [C.c_void_p]
+        L.murbhip_warmup.argtypes = [C.c_void_p, C.c_double]
         L.murbhip_step.argtypes = [C.c_void_p, C.c_float]
         L.murbhip_steps.argtypes = [C.c_void_p, C.c_float, C.c_int]
         L.murbhip_integrate_host_acc.argtypes = [C.c_void_p] + [_fp] * 3 + [C.c_float]
@@ -78,7 +79,7 @@ EXPORTS = ("murbhip_version murbhip_error_string murbhip_partition murbhip_slice
            "murbhip_schedule_items murbhip_schedule_layout "
            "murbhip_device_count murbhip_create murbhip_create_sharded murbhip_unique_id murbhip_create_rank "
            "murbhip_destroy murbhip_upload murbhip_init_bodies murbhip_download_mass murbhip_download_state murbhip_download_acc murbhip_compute_acc "
-           "murbhip_step murbhip_steps murbhip_integrate_host_acc murbhip_sync murbhip_energy murbhip_moments murbhip_set_option "
+           "murbhip_warmup murbhip_step murbhip_steps murbhip_integrate_host_acc murbhip_sync murbhip_energy murbhip_moments murbhip_set_option "
            "murbhip_get_info").split()
 
 
@@ -204,6 +205,10 @@ class Simulation:
     # -- compute (enqueue only; sync() waits)
     def compute_acc(self):
         _check(lib().murbhip_compute_acc(self._h), "murbhip_compute_acc")
+
+    def warmup(self, milliseconds=50.0):
+        """Untimed force evaluations on the current state (include/murbhip.h: murbhip_warmup); syncs."""
+        _check(lib().murbhip_warmup(self._h, milliseconds), "murbhip_warmup")
 
     def step(self, dt=3600.0):
         _check(lib().murbhip_step(self._h, dt), "murbhip_step")

@@ -1027,6 +1027,35 @@ def test_energy_from_the_force_evaluation(gpu, O, scheme, n, devices):
         assert abs(p1 - p2) <= 5e-7 * abs(p2) and abs(k1 - k2) <= 1e-12 * abs(k2)
 
 
+@pytest.mark.parametrize("n,devices", [(3000, [0]), (30000, [0]), (30000, [0, 0, 0])])
+def test_warmup_changes_nothing(gpu, O, n, devices):
+    """murbhip_warmup: untimed force evaluations before a caller's first timed iteration.  The state is untouched, nothing
+    is remembered (the step that follows launches its own force evaluation), the trajectory is bit-identical."""
+    s = O.init_bodies(n, "galaxy")
+    kw = {"devices": devices} if len(devices) > 1 else {}
+    with gpu.Simulation(n, soft=SOFT, **kw) as plain, gpu.Simulation(n, soft=SOFT, **kw) as warm:
+        for sim in (plain, warm):
+            sim.upload(s)
+        warm.warmup(20.0)
+        a, b = plain.state(), warm.state()
+        for k in a:
+            assert np.array_equal(bits(a[k]), bits(b[k])), k
+        warm.set_option("profile", 1)
+        plain.set_option("profile", 1)
+        for sim in (plain, warm):
+            sim.steps(DT, 3)
+            sim.sync()
+        assert warm.info("force_launches") == plain.info("force_launches") > 0
+        warm.warmup(5.0)                                   # between steps as well
+        for sim in (plain, warm):
+            sim.step(DT)
+        a, b = plain.state(), warm.state()
+        for k in a:
+            assert np.array_equal(bits(a[k]), bits(b[k])), k
+        with pytest.raises(gpu.MurbHipError):
+            warm.warmup(-1.0)
+
+
 @pytest.mark.parametrize("n,shards", [(29, 8), (132, 8), (300, 1), (300, 8), (1025, 2), (2500, 3)])
 def test_fused_potential_with_few_bodies(gpu, O, n, shards):
     """The galaxy's central body is 10^4 times heavier than the rest: with a few dozen bodies its own term (G m)^2 / soft is
