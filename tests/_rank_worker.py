@@ -20,10 +20,16 @@ with murbhip.Simulation(n, soft=2e8, device=0, rank=rank, world=world, uid=uid) 
     sim.set_option("overlap", overlap)
     sim.set_option("jsplit", jsplit)
     sim.set_option("integrator", integrator)
+    warmup_ms = 0.0
     for kv in filter(None, os.environ.get("MURB_TEST_OPTIONS", "").split(",")):   # further library options: "key=value,key=value"
         key, value = kv.split("=")
-        sim.set_option(key, int(value))
+        if key == "warmup":           # not an option: murbhip_warmup for that many ms after the upload (collectives inside)
+            warmup_ms = float(value)
+        else:
+            sim.set_option(key, int(value))
     sim.upload(s)
+    if warmup_ms:
+        sim.warmup(warmup_ms)
     sim.compute_acc()
     sim.sync()
     acc0 = sim.acc()                 # own bodies only; zeros elsewhere

@@ -110,7 +110,8 @@ def test_ranks_match_single_gpu(gpu, O, tmp_path, world, n, variant, overlap, js
     assert abs(sum(float(d["pe"]) for d in ranks) - pe) <= 1e-5 * abs(pe)
 
 
-@pytest.mark.parametrize("world,n,overlap,options", [(4, 20000, 1, ""), (3, 15000, 2, ""), (4, 20000, 1, "exchange_p2p=1")])
+@pytest.mark.parametrize("world,n,overlap,options", [(4, 20000, 1, ""), (3, 15000, 2, ""), (4, 20000, 1, "exchange_p2p=1"),
+                                                     (3, 15000, 1, "warmup=3")])   # murbhip_warmup: the same count of collectives on every rank
 def test_long_rank_mode_run_with_asynchronous_collectives(gpu, O, tmp_path, world, n, overlap, options):
     """300 steps, every one with a reduce-scatter and an all-gather that only ENQUEUE work on the library's exchange stream
     (the stand-in's async mode): a missing dependency between the compute and exchange streams — reading positions before
