@@ -52,6 +52,12 @@ namespace {
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
 inline int nccl_rc(int r) { return r == 0 ? 0 : -(3000 + r); }   // disjoint from -(hipError_t), which reaches past 1000
 
+// Teardown and error paths: a release that fails cannot be acted on (the context is going away either way).
+template <typename... P> inline void release(P*... p) { ((void)hipFree((void*)p), ...); }
+inline void release_event(hipEvent_t& e) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+inline void release_stream(hipStream_t& s) { if (s) (void)hipStreamDestroy(s); s = nullptr; }
+inline void drain(hipStream_t s) { if (s) (void)hipStreamSynchronize(s); }
+
 #define HIP_TRY(expr)                        \
     do {                                     \
         const int rc_ = hip_rc((expr));      \
@@ -633,7 +639,7 @@ int ensure_accp(murbhip_ctx* c, Shard& sh)
 
 void free_sym_set(SymSet& st)
 {
-    hipFree(st.part); hipFree(st.rows);
+    release(st.part, st.rows);
     st = SymSet{};
 }
 
@@ -692,7 +698,7 @@ int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p)
     const bool exchange_mode = c->world > 1 || c->force_exchange;
     sh.sym_red = p.red;
     if (!sym_schedule_stale(c, sh, p)) return 0;
-    hipFree(sh.sym_items); sh.sym_items = nullptr;
+    release(sh.sym_items); sh.sym_items = nullptr;
     free_sym_set(sh.sym_main);
     free_sym_set(sh.sym_tri);
     sh.bytes -= sh.sym_bytes;
@@ -1144,7 +1150,7 @@ int create_common(murbhip_ctx** out, unsigned long n, float soft, float g, int w
             for (Shard& b : c->shards)
                 if (a.device != b.device) {
                     int can = 0;
-                    hipSetDevice(a.device);
+                    if ((rc = hip_rc(hipSetDevice(a.device)))) break;
                     if (hipDeviceCanAccessPeer(&can, a.device, b.device) == hipSuccess && can) {
                         hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
                         if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) rc = hip_rc(e);
@@ -1346,8 +1352,8 @@ int murbhip_create_rank(murbhip_ctx** out, unsigned long n, float soft, float g,
     if (world > 1 || unique_id) {   // a one-rank communicator is legal and exercises the whole RCCL binding
         rccl_id_t id;
         std::memcpy(&id, unique_id, sizeof id);
-        hipSetDevice(device);
-        const int rc = nccl_rc(rccl().CommInitRank(&(*out)->shards[0].comm_rccl, world, id, rank));
+        int rc = hip_rc(hipSetDevice(device));
+        if (rc == 0) rc = nccl_rc(rccl().CommInitRank(&(*out)->shards[0].comm_rccl, world, id, rank));
         if (rc != 0) { murbhip_destroy(*out); *out = nullptr; return rc; }
     }
     return 0;
@@ -1359,22 +1365,15 @@ int murbhip_destroy(murbhip_ctx* c)
     delete c->crew;   // joins the shards' threads (idle: every entry point returns only when they have finished enqueueing)
     c->crew = nullptr;
     for (Shard& sh : c->shards) {
-        hipSetDevice(sh.device);
-        if (sh.compute) hipStreamSynchronize(sh.compute);
-        if (sh.comm) hipStreamSynchronize(sh.comm);
-        if (sh.compute_low) { hipStreamSynchronize(sh.compute_low); hipStreamDestroy(sh.compute_low); }
-        if (sh.ev_tri) hipEventDestroy(sh.ev_tri);
+        (void)hipSetDevice(sh.device);
+        drain(sh.compute); drain(sh.comm); drain(sh.compute_low);
         if (sh.comm_rccl && rccl().ok) rccl().CommDestroy(sh.comm_rccl);
-        for (hipEvent_t e : sh.prof) hipEventDestroy(e);
-        if (sh.ev_integrated) hipEventDestroy(sh.ev_integrated);
-        if (sh.ev_gathered) hipEventDestroy(sh.ev_gathered);
-        if (sh.compute) hipStreamDestroy(sh.compute);
-        if (sh.comm) hipStreamDestroy(sh.comm);
-        hipFree(sh.rec[0]); hipFree(sh.rec[1]); hipFree(sh.vel); hipFree(sh.accp); hipFree(sh.acc_out); hipFree(sh.phi_out); hipFree(sh.mass); hipFree(sh.radius); hipFree(sh.metrics);
-        hipFree(sh.sym_items); free_sym_set(sh.sym_main); free_sym_set(sh.sym_tri);
-        hipFree(sh.sym_send); hipFree(sh.sym_recv); hipFree(sh.sym_p2p); hipFree(sh.sym_tri_acc); hipFree(sh.sym_acc64);
-        if (sh.ev_rowsum) hipEventDestroy(sh.ev_rowsum);
-        if (sh.ev_reduced) hipEventDestroy(sh.ev_reduced);
+        for (hipEvent_t& e : sh.prof) release_event(e);
+        for (hipEvent_t* e : {&sh.ev_tri, &sh.ev_integrated, &sh.ev_gathered, &sh.ev_rowsum, &sh.ev_reduced}) release_event(*e);
+        for (hipStream_t* q : {&sh.compute_low, &sh.compute, &sh.comm}) release_stream(*q);
+        release(sh.rec[0], sh.rec[1], sh.vel, sh.accp, sh.acc_out, sh.phi_out, sh.mass, sh.radius, sh.metrics);
+        release(sh.sym_items, sh.sym_send, sh.sym_recv, sh.sym_p2p, sh.sym_tri_acc, sh.sym_acc64);
+        free_sym_set(sh.sym_main); free_sym_set(sh.sym_tri);
     }
     delete c;
     return 0;
@@ -1483,7 +1482,7 @@ int murbhip_init_bodies(murbhip_ctx* c, const char* scheme, unsigned long seed)
             rc = hip_rc(hipGetLastError());
         }
         const int rs = hip_rc(hipStreamSynchronize(sh.compute));
-        hipFree(d_draws);
+        release(d_draws);
         if (rc || rs) return rc ? rc : rs;
         sh.prof_used = 0;
     }
