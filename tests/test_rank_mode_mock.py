@@ -164,6 +164,8 @@ def test_bench_py_with_several_ranks(gpu, world, n):
                MURB_BENCH_OTHER_CONFIGS="30000:10,60000:5",   # stand-ins for BASELINE's other sizes (the ranks share one GPU here)
                MURB_BENCH_UNTIMED_SCALE="0.1")                # ... and every step pays a host-staged collective: fewer untimed steps
     env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)               # bench.py must set it itself in this launch path
+    if world > 2:   # the one-process diagnostic runs in a child of rank 0: with 4 ranks, the launcher and this test that is one
+        env["MURB_BENCH_NO_ONE_PROCESS"] = "1"                # process more on GPU 0 than the test box allows (6)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--bodies",
            str(n), "--steps", "10", "--warmup", "2"]
@@ -195,9 +197,13 @@ def test_bench_py_with_several_ranks(gpu, world, n):
     assert alt["ms_per_step"] > 0 and abs(alt["half_ring_speedup"] - alt["ms_per_step"] / d["ms_per_step"]) < 1e-9
     p2p = d["p2p_plan"]                # both exchanges as grouped sends / receives, timed beside the collectives
     assert p2p["ms_per_step"] > 0 and abs(p2p["speedup_over_collectives"] - p2p["collectives_ms_per_step_same_context"] / p2p["ms_per_step"]) < 1e-9
-    one = d["one_process_plan"]         # the drop-in form: rank 0 alone drives all shards from one process, both exchanges
-    for ex in ("copy", "rccl"):
-        assert one[ex]["ms_per_step"] > 0 and one[ex]["ms_per_step_sync_each_iteration"] > 0 and one[ex]["kernel_variant"] == 8, one
+    if world <= 2:
+        one = d["one_process_plan"]     # the drop-in form: ONE process (a child of rank 0) drives all shards, both exchanges
+        for ex in ("copy", "rccl"):
+            assert one[ex]["ms_per_step"] > 0 and one[ex]["ms_per_step_sync_each_iteration"] > 0 and one[ex]["kernel_variant"] == 8, one
+            assert one["vs_one_process_per_gpu"][ex] > 0
+    else:
+        assert "one_process_plan" not in d
     oc = {e["n_bodies"]: e for e in d["other_configs"]}
     assert set(oc) == {30000, 60000}
     for e in oc.values():
@@ -265,6 +271,25 @@ def test_bench_py_keeps_the_measurement_when_an_extra_fails(gpu):
     assert d["value"] > 0 and d["n_gpus"] == 2 and d["rank_mode_check"]["positions_identical_on_all_ranks"] and "exchange" in d
     assert "injected failure" in d["incomplete"]["error"] and d["incomplete"]["phase"].startswith("other config")
     assert r.returncode == 0, r.stderr[-1500:]
+
+
+def test_bench_py_keeps_the_measurement_when_rank_0_is_killed(gpu):
+    """N > 1: rank 0 ended the hard way (abort() inside a library, a GPU fault: nothing Python can catch) during a diagnostic
+    AFTER the main measurement.  The line it had sent to its keeper process by then still reaches stdout — ONE line, with the
+    measurement and an "incomplete" note; the exit code says that the run did not end well."""
+    import json
+    env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK, MURB_BENCH_BACKEND="gloo", MURB_BENCH_SHARE_GPU="1", MURB_BENCH_UNTIMED_SCALE="0.1",
+               MURB_BENCH_OTHER_CONFIGS="30000:10", MURB_BENCH_ABORT_IN="other config", MURB_BENCH_PHASE_LIMIT_S="60")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bodies", "40000", "--steps", "6", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, (r.stdout, r.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["n_gpus"] == 2 and d["rank_mode_check"]["positions_identical_on_all_ranks"] and "exchange" in d
+    assert "process ended before the diagnostics" in d["incomplete"]["error"]
+    assert r.returncode != 0
 
 
 def test_bench_py_reports_a_failed_start(gpu):
