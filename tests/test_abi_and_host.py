@@ -303,6 +303,33 @@ def test_shard_crew_selftest(binary, members, rounds):
     assert r.returncode == 0 and r.stdout.strip() == "ok" and "ThreadSanitizer" not in r.stderr, (r.stdout, r.stderr[-2000:])
 
 
+@pytest.mark.parametrize("ending", ["abort", "kill", "normal"])
+def test_bench_last_line_keeper(ending):
+    """bench.py's LastLineKeeper without a GPU: whatever ends the writing process — abort(), SIGKILL, or a normal end — stdout
+    carries exactly ONE line, the last one that was sent (rank 0 of an N > 1 run sends its line once when the main measurement
+    is complete and again at the very end)."""
+    import sys
+    end = {"abort": "os.abort()", "kill": "os.kill(os.getpid(), 9)", "normal": "k.close_and_wait()"}[ending]
+    code = (
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "k = bench.LastLineKeeper(os.fdopen(os.dup(1), 'w'))\n"
+        "os.dup2(2, 1)\n"
+        "k.write('{\"value\": 1, \"incomplete\": true}\\n'); k.flush()\n"
+        "print('library chatter on the C-level stdout')\n"
+        "k.write('{\"value\": 1, \"pad\": \"' + 'x' * 200000 + '\"}\\n'); k.flush()\n"
+        "%s\n"
+    ) % (ROOT, end)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, (r.stdout[:300], r.stderr[-1000:])
+    import json
+    d = json.loads(lines[0])
+    assert d["value"] == 1 and len(d["pad"]) == 200000 and "incomplete" not in d
+    assert (r.returncode == 0) == (ending == "normal")
+
+
 def test_bench_host_facts_and_roofline_arithmetic():
     """bench.py without a GPU: the host's share is read at import, BEFORE OpenMP can narrow the main thread's affinity mask
     (usable cores = physical cores in the mask, capped by the cgroup CPU quota) and becomes the CPU baseline's thread count; and
