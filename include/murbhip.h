@@ -203,11 +203,13 @@ int murbhip_sync(murbhip_ctx* ctx);
  * G m_i G m_j / r of every pair a wave meets, one float per group of 4 i bodies behind the partial rows, fp64 from there on —
  * so there is no second N^2 sweep; the forces of that evaluation are remembered (bit-identical to a plain evaluation's),
  * and a step that follows directly only launches the state update (with several shards: state update + position
- * exchange).  A tracked iteration (energy, then step: `--im hip+tracking`) therefore costs ONE force evaluation: 7.4 ms
- * instead of 10.0 at N = 200 000.  In rank mode the potential covers the PAIRS this rank evaluated under the half-ring
+ * exchange).  A tracked iteration (energy, then step: `--im hip+tracking`) therefore costs ONE force evaluation: 6.9 ms
+ * instead of 10.2 at N = 200 000 (6.1 untracked).  The pairs INSIDE a block of 1024 bodies are summed by a small kernel of their
+ * own, in fp64 and without the bodies' own terms: the result is within 3e-8 of an fp64 evaluation from a few dozen bodies up.
+ * Under the multi-pass evaluation (N > 2.4 M) the groups' sums are added up pass by pass.  In rank mode the potential covers the PAIRS this rank evaluated under the half-ring
  * schedule, the kinetic energy its own bodies: sum both over the ranks; the call is a collective (the force evaluation
  * contains the reduce-scatter) unless the forces of the current positions are already remembered.
- * One-sided plan (small N), several passes (N > 2.4 M) or option "energy_sweep" 1: one N^2 potential sweep on the device
+ * One-sided plan (below 2 049 bodies; few bodies per rank) or option "energy_sweep" 1: one N^2 potential sweep on the device
  * (phi_i = sum_j G m_j / r), then -1/2 sum m_i phi_i; values cover the caller's own bodies.
  * The per-body terms are summed in fp64 on the device (256-body block sums in a fixed order; the host adds the few hundred
  * block rows); waits for enqueued steps. */

@@ -603,7 +603,8 @@ __global__ __launch_bounds__(256) void murb_sym_pe_diag_kernel(const float4* rec
 // Sum of the groups' pair potentials of a set of launches (PHI = 2: `count` floats behind the three components of the partial
 // rows, zero where no item has groups) in fp64, in a fixed order: thread t adds entries t, t + 1024 x blocks, ...; every
 // workgroup folds its 1024 partial sums through LDS and writes one double; the host adds the few hundred of them.
-__global__ __launch_bounds__(1024) void murb_sym_pe_sum_kernel(const float* pe, unsigned long count, double* out)
+// accumulate: add to what `out` holds (the later passes of a multi-pass evaluation, whose launches share the buffer).
+__global__ __launch_bounds__(1024) void murb_sym_pe_sum_kernel(const float* pe, unsigned long count, double* out, int accumulate)
 {
     __shared__ double red[1024];
     double acc = 0.0;
@@ -614,7 +615,7 @@ __global__ __launch_bounds__(1024) void murb_sym_pe_sum_kernel(const float* pe, 
         if ((int)threadIdx.x < half) red[threadIdx.x] += red[threadIdx.x + half];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+    if (threadIdx.x == 0) out[blockIdx.x] = (accumulate ? out[blockIdx.x] : 0.0) + red[0];
 }
 
 // Point-to-point form of the reduce-scatter ("exchange_p2p"): out = this rank's own contribution to its slice + the chunks

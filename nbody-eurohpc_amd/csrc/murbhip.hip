@@ -466,6 +466,25 @@ int timed_wait(murbhip_ctx* c, Shard& sh, int kind, hipStream_t stream, hipEvent
 
 int build_sym_schedule(murbhip_ctx* c, Shard& sh, const Plan& p);
 int ensure_accp(murbhip_ctx* c, Shard& sh);
+// What a shard's read-out buffer (Shard::metrics) holds, in doubles: the block rows of murb_metrics_kernel, then the pair
+// potentials of murbhip_energy — the partial sums of the two sets' groups (murb_sym_pe_sum_kernel) and the own slice's
+// diagonal blocks (murb_sym_pe_diag_kernel).  One buffer so that one copy brings a tracked iteration's numbers to the host.
+struct MetricsLayout {
+    size_t blocks, rows, pe_main, pe_tri, pe_diag, own_blocks, total;
+};
+MetricsLayout metrics_layout(const murbhip_ctx* c)
+{
+    MetricsLayout l{};
+    l.blocks = (c->slice + 255) / 256;
+    l.rows = 0;
+    l.pe_main = l.blocks * MURB_METRIC_VALUES;
+    l.pe_tri = l.pe_main + kPeSumBlocks;
+    l.pe_diag = l.pe_tri + kPeSumBlocks;
+    l.own_blocks = c->slice / MURB_SYM_BLOCK;
+    l.total = l.pe_diag + l.own_blocks * MURB_PE_DIAG_SPLIT;
+    return l;
+}
+
 int enqueue_sym_passes(murbhip_ctx* c, Shard& sh, bool potential);
 int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own_triangle_rows = false,
                        hipStream_t stream = nullptr, bool potential = false, size_t comp_stride = 0, int kind = kProfForce);
@@ -962,8 +981,22 @@ int shard_iteration_sym_multi(murbhip_ctx* c, Shard& sh, const Plan& p, float dt
 int enqueue_sym_passes(murbhip_ctx* c, Shard& sh, bool potential)
 {
     HIP_TRY(hipMemsetAsync(sh.sym_acc64, 0, 3 * c->slots * sizeof(double), sh.compute));
+    // force + pair potential (murbhip_energy): every pass has a layout of its own in the shared buffer, so the plane of the
+    // groups' potentials — one float per group of the pass's i rows, zero elsewhere — is cleared before the pass and summed
+    // right after it, into the same doubles of the read-out buffer pass after pass
+    const bool with_pe = !potential && c->want_pe && sh.metrics;
+    bool first = true;
     for (const SymPass& ps : sh.sym_main.passes) {
+        float* const pe_plane = sh.sym_main.part + 3 * ps.floats;
+        const size_t pe_count = ps.floats / MURB_SYM_R + 1;
+        if (with_pe) HIP_TRY(hipMemsetAsync(pe_plane, 0, pe_count * sizeof(float), sh.compute));
         RC_TRY(enqueue_sym_launch(c, sh, ps.item_first, ps.item_count, false, nullptr, potential, ps.floats));
+        if (with_pe) {
+            hipLaunchKernelGGL(murb_sym_pe_sum_kernel, dim3(kPeSumBlocks), dim3(1024), 0, sh.compute, pe_plane, (unsigned long)pe_count,
+                               sh.metrics + metrics_layout(c).pe_main, first ? 0 : 1);
+            RC_TRY(hip_rc(hipGetLastError()));
+            first = false;
+        }
         hipLaunchKernelGGL(murb_sym_rowsum_acc_kernel, dim3((unsigned)ps.table_count * (MURB_SYM_BLOCK / 64)), dim3(MURB_ROWSUM_THREADS), 0,
                            sh.compute, sh.sym_main.part, ps.floats, sh.sym_main.rows + ps.table_first, sh.sym_acc64, (unsigned int)c->slots);
         RC_TRY(hip_rc(hipGetLastError()));
@@ -1691,25 +1724,6 @@ int ensure_acc_for_readout(murbhip_ctx* c)
     return 0;
 }
 
-// What a shard's read-out buffer (Shard::metrics) holds, in doubles: the block rows of murb_metrics_kernel, then the pair
-// potentials of murbhip_energy — the partial sums of the two sets' groups (murb_sym_pe_sum_kernel) and the own slice's
-// diagonal blocks (murb_sym_pe_diag_kernel).  One buffer so that one copy brings a tracked iteration's numbers to the host.
-struct MetricsLayout {
-    size_t blocks, rows, pe_main, pe_tri, pe_diag, own_blocks, total;
-};
-MetricsLayout metrics_layout(const murbhip_ctx* c)
-{
-    MetricsLayout l{};
-    l.blocks = (c->slice + 255) / 256;
-    l.rows = 0;
-    l.pe_main = l.blocks * MURB_METRIC_VALUES;
-    l.pe_tri = l.pe_main + kPeSumBlocks;
-    l.pe_diag = l.pe_tri + kPeSumBlocks;
-    l.own_blocks = c->slice / MURB_SYM_BLOCK;
-    l.total = l.pe_diag + l.own_blocks * MURB_PE_DIAG_SPLIT;
-    return l;
-}
-
 // The O(N) sums of the tracked metrics over this process's bodies (murb_metrics_kernel + the block rows added
 // in index order on the host).  want_phi: the potential sweep has just been written to phi_out.  pair_sum: also add up
 // the pair potentials murbhip_energy has just enqueued into the buffers' tails (then the kept sums are not enough).
@@ -1769,15 +1783,21 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
     if (!c || !kinetic || !potential) return MURBHIP_E_INVALID;
     if (!c->uploaded) return MURBHIP_E_STATE;
     const Plan main_plan = make_plan(c);
-    bool one_pass = true;
-    for (const Shard& sh : c->shards) one_pass = one_pass && sh.sym_main.passes.size() <= 1;
-    if (main_plan.symmetric && !c->energy_sweep && one_pass) {
+    if (main_plan.symmetric && !c->energy_sweep) {
         // Pair-symmetric plan: the potential energy comes out of a FORCE evaluation (murb_kernels_sym.h, PHI = 2: two more
         // packed instructions per 18 sum G m_i G m_j / r of every pair a wave meets, one float per group of 4 i bodies behind
         // the partial rows) — no second N^2 sweep.  The forces of that evaluation are remembered, so a step that follows only
         // launches the state update (also with several shards): a tracked iteration costs one force evaluation.  Every shard
         // sums the pairs IT evaluated off the diagonal, plus the pairs inside its own blocks (murb_sym_pe_diag_kernel: fp64,
-        // no self terms).  (Several passes over one shared buffer, N > 2.4 M: the separate sweep below.)
+        // no self terms).  Several passes over one shared buffer (one GPU, N > 2.4 M): the groups' sums are added up pass by
+        // pass while the evaluation runs (enqueue_sym_passes).
+        const MetricsLayout l = metrics_layout(c);
+        for (Shard& sh : c->shards) {
+            if (sh.metrics) continue;
+            HIP_TRY(hipSetDevice(sh.device));
+            HIP_TRY(hipMalloc((void**)&sh.metrics, l.total * sizeof(double)));
+            sh.bytes += l.total * sizeof(double);
+        }
         if (!(c->acc_current && c->pe_current)) {
             c->acc_current = false;   // forces alone are not enough: evaluate again, this time with the pair potential
             c->want_pe = true;
@@ -1785,38 +1805,27 @@ int murbhip_energy(murbhip_ctx* c, double* kinetic, double* potential)
             c->want_pe = false;
             RC_TRY(rc);
         }
-        bool still_one_pass = true;   // the evaluation above may have built the tables for the first time
-        for (const Shard& sh : c->shards) still_one_pass = still_one_pass && sh.sym_main.passes.size() <= 1;
-        if (still_one_pass) {
-            const MetricsLayout l = metrics_layout(c);
-            for (Shard& sh : c->shards) {
-                HIP_TRY(hipSetDevice(sh.device));
-                if (!sh.metrics) {
-                    HIP_TRY(hipMalloc((void**)&sh.metrics, l.total * sizeof(double)));
-                    sh.bytes += l.total * sizeof(double);
-                }
-                const size_t at[2] = {l.pe_main, l.pe_tri};
-                int k = 0;
-                for (SymSet* st : {&sh.sym_main, &sh.sym_tri}) {
-                    const size_t off = at[k++];
-                    if (!st->part) continue;
-                    hipLaunchKernelGGL(murb_sym_pe_sum_kernel, dim3(kPeSumBlocks), dim3(1024), 0, sh.compute, st->part + 3 * st->comp_stride,
-                                       (unsigned long)(st->comp_stride / MURB_SYM_R + 1), sh.metrics + off);
-                    RC_TRY(hip_rc(hipGetLastError()));
-                }
-                // the diagonal blocks (the own slice's) separately, in fp64 and without the bodies' own terms
-                hipLaunchKernelGGL(murb_sym_pe_diag_kernel, dim3((unsigned)(l.own_blocks * MURB_PE_DIAG_SPLIT)), dim3(256), 0, sh.compute, sh.rec[c->cur],
-                                   (int)(sh.rank * l.own_blocks), c->soft2, sh.metrics + l.pe_diag);
+        for (Shard& sh : c->shards) {
+            HIP_TRY(hipSetDevice(sh.device));
+            const size_t at[2] = {l.pe_main, l.pe_tri};
+            int k = 0;
+            for (SymSet* st : {&sh.sym_main, &sh.sym_tri}) {
+                const size_t off = at[k++];
+                if (!st->part || st->passes.size() > 1) continue;   // several passes: summed during the evaluation
+                hipLaunchKernelGGL(murb_sym_pe_sum_kernel, dim3(kPeSumBlocks), dim3(1024), 0, sh.compute, st->part + 3 * st->comp_stride,
+                                   (unsigned long)(st->comp_stride / MURB_SYM_R + 1), sh.metrics + off, 0);
                 RC_TRY(hip_rc(hipGetLastError()));
             }
-            double sums[MURB_METRIC_VALUES], pair_sum = 0.0;
-            RC_TRY(device_metrics(c, false, sums, &pair_sum));   // syncs; one copy per shard
-            const double g = (double)c->g;
-            *kinetic = sums[0];
-            *potential = -pair_sum / g;
-            return 0;
+            // the diagonal blocks (the own slice's) separately, in fp64 and without the bodies' own terms
+            hipLaunchKernelGGL(murb_sym_pe_diag_kernel, dim3((unsigned)(l.own_blocks * MURB_PE_DIAG_SPLIT)), dim3(256), 0, sh.compute, sh.rec[c->cur],
+                               (int)(sh.rank * l.own_blocks), c->soft2, sh.metrics + l.pe_diag);
+            RC_TRY(hip_rc(hipGetLastError()));
         }
-        c->pe_current = false;   // several passes after all: fall through to the sweep (the forces stay remembered)
+        double sums[MURB_METRIC_VALUES], pair_sum = 0.0;
+        RC_TRY(device_metrics(c, false, sums, &pair_sum));   // syncs; one copy per shard
+        *kinetic = sums[0];
+        *potential = -pair_sum / (double)c->g;
+        return 0;
     }
     // phi_i = sum_j GM_j / sqrt(r_ij^2 + soft^2) over ALL j (self term included), written to the x plane of phi_out:
     // pair-symmetric sweep where the force plan is pair-symmetric (one GPU: one launch; several ranks: the half-ring

@@ -204,10 +204,23 @@ def test_multi_pass_evaluation(gpu, O, n, budget_mb, opts):
         # same partial sums, fp64 additions regrouped; with "xcd_order" the single-pass run keeps the interleaved item order
         # (other tail items, other partial sums) while the passes fall back to the j-major one: fp32 noise between them
         assert O.rel_err(multi.acc(), one.acc()).max() <= (6e-7 if opts.get("xcd_order") else 2e-7)
-        # the single-pass run takes the pair potential out of its force evaluation, the multi-pass one (one shared row buffer)
-        # runs the separate potential sweep: two fp32 evaluations of the same sum, each within ~2e-7 of the fp64 value
+        # both take the pair potential out of their force evaluation (the multi-pass one adds the groups' sums up pass by pass:
+        # every pass has a layout of its own in the shared buffer) — and no second N^2 launch for it in either
+        ke, pe = O.energy_f64(s, SOFT)
+        for sim in (one, multi):
+            sim.set_option("profile", 1)
         (k1, p1), (k2, p2) = one.energy(), multi.energy()
-        assert abs(p2 - p1) <= 5e-7 * abs(p1) and abs(k2 - k1) <= 1e-7 * abs(k1)
+        assert abs(p1 - pe) <= 1e-7 * abs(pe) and abs(p2 - pe) <= 1e-7 * abs(pe), ((p1 - pe) / pe, (p2 - pe) / pe)
+        assert abs(k2 - k1) <= 1e-12 * abs(k1) and abs(k1 - ke) <= 1e-9 * abs(ke)
+        assert one.info("sym_launches") == 1 and multi.info("sym_launches") == multi.info("sym_passes")
+        (k3, p3) = multi.energy()                      # nothing changed: the remembered sums, no launch
+        assert p3 == p2 and multi.info("sym_launches") == multi.info("sym_passes")
+        multi.set_option("energy_sweep", 1)            # the separate sweep of rounds 1-2 as a cross-check
+        (k4, p4) = multi.energy()
+        assert abs(p4 - pe) <= 5e-7 * abs(pe)
+        multi.set_option("energy_sweep", 0)
+        for sim in (one, multi):
+            sim.set_option("profile", 0)
         one.steps(DT, 3); multi.steps(DT, 3)
         one.sync(); multi.sync()
         s1, s2 = one.state(), multi.state()
