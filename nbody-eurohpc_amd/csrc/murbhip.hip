@@ -1227,7 +1227,7 @@ void pack_records(const murbhip_ctx* c, const float* x, const float* y, const fl
 // ===================================================================================== C ABI
 extern "C" {
 
-int murbhip_version(void) { return 102; }   // 1.02: per-shard host threads, "profile" 2 and the span_* facts
+int murbhip_version(void) { return 103; }   // 1.03: murbhip_warmup, murbhip_init_bodies, the potential out of the force evaluation
 
 const char* murbhip_error_string(int code)
 {
