@@ -162,7 +162,8 @@ def test_bench_py_with_several_ranks(gpu, world, n):
         subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "helpers")], check=True, timeout=600)
     env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK, MURB_BENCH_BACKEND="gloo", MURB_BENCH_SHARE_GPU="1",
                MURB_BENCH_OTHER_CONFIGS="30000:10,60000:5",   # stand-ins for BASELINE's other sizes (the ranks share one GPU here)
-               MURB_BENCH_UNTIMED_SCALE="0.1")                # ... and every step pays a host-staged collective: fewer untimed steps
+               MURB_BENCH_UNTIMED_SCALE="0.1",                # ... and every step pays a host-staged collective: fewer untimed steps
+               MURB_BENCH_KEEP_PLAN="1")                      # ... which makes the reduce-scatter dear: the tuner would (rightly) switch plans
     env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)               # bench.py must set it itself in this launch path
     if world > 2:   # the one-process diagnostic runs in a child of rank 0: with 4 ranks, the launcher and this test that is one
         env["MURB_BENCH_NO_ONE_PROCESS"] = "1"                # process more on GPU 0 than the test box allows (6)
@@ -181,6 +182,7 @@ def test_bench_py_with_several_ranks(gpu, world, n):
     assert "cpu_baseline" not in d      # rank 0 at N = 1 only
     assert d["tuned"]["tri_first_pct"] in (0, 25, 50, 75, 100) and len(d["tuned"]["ms_per_step_by_candidate"]) == 5
     assert d["tuned"]["cu_reserve"] in (0, 8, 16) and len(d["tuned"]["ms_per_step_by_cu_reserve"]) == 3
+    assert "half-ring" in d["config"]["parallelism"] and "plan" not in d["tuned"]     # MURB_BENCH_KEEP_PLAN
     # a first real multi-GPU run must explain itself: both collectives and the compute stream's waits for them, event-timed
     # on rank 0's streams; the one-sided (all-gather only) plan timed beside the half-ring one; the other sizes
     ex = d["exchange"]
@@ -271,6 +273,29 @@ def test_bench_py_keeps_the_measurement_when_an_extra_fails(gpu):
     assert d["value"] > 0 and d["n_gpus"] == 2 and d["rank_mode_check"]["positions_identical_on_all_ranks"] and "exchange" in d
     assert "injected failure" in d["incomplete"]["error"] and d["incomplete"]["phase"].startswith("other config")
     assert r.returncode == 0, r.stderr[-1500:]
+
+
+def test_bench_py_takes_the_one_sided_plan_when_it_wins(gpu):
+    """N > 1: where the all-gather-only plan beats the half-ring schedule in the untimed tuning steps (a node whose
+    reduce-scatter costs more than it saves) the timed region runs it.  Forced here: the line must then describe THAT plan
+    (one-sided kernel, no reduce-scatter span), carry the forced half-ring schedule as the other plan, and still pass its check."""
+    import json
+    env = dict(os.environ, MURBHIP_RCCL_LIBRARY=MOCK, MURB_BENCH_BACKEND="gloo", MURB_BENCH_SHARE_GPU="1", MURB_BENCH_UNTIMED_SCALE="0.1",
+               MURB_BENCH_OTHER_CONFIGS="30000:10", MURB_BENCH_TAKE_ONE_SIDED="1", MURB_BENCH_NO_ONE_PROCESS="1", MURB_BENCH_NO_P2P="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bodies", "40000", "--steps", "6", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, (r.stdout, r.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["config"]["kernel_variant"] == 1 and "one-sided" in d["config"]["parallelism"]
+    assert d["tuned"]["plan"].startswith("one-sided") and d["tuned"]["ms_per_step_one_sided_plan"] > 0 and d["tuned"]["ms_per_step_half_ring_plan"] > 0
+    assert d["rank_mode_check"]["positions_identical_on_all_ranks"] and d["rank_mode_check"]["max_position_diff_rel"] < 1e-5
+    assert d["exchange"]["all_gather_ms_avg"] > 0 and d["exchange"]["plan"].startswith("one-sided")
+    assert d["one_sided_plan"]["kernel_variant"] == 8 and d["one_sided_plan"]["ms_per_step"] > 0
+    assert d["roofline"]["frac"] < 1.0 and "incomplete" not in d
 
 
 def test_bench_py_keeps_the_measurement_when_rank_0_is_killed(gpu):
