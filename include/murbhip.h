@@ -228,8 +228,9 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
 
 /* Integer options.  Keys:
  *   "variant"        force kernel variant.  0 = auto: the pair-symmetric kernel (8) on one
- *                    GPU from 2 049 bodies (3 blocks of 1024) up and in multi-GPU runs when a rank gets >= 400 block
- *                    pairs, the one-sided kernel (1) otherwise.  1-6: one-sided variants, 7: persistent schedule
+ *                    GPU from 4 097 bodies (5 blocks of 1024) up, except at 6 blocks, and in multi-GPU runs when a rank gets
+ *                    >= 400 block pairs, the one-sided kernel (1) otherwise (one GPU: with the state update in the tail of
+ *                    its launch, see "fuse_integrate").  1-6: one-sided variants, 7: persistent schedule
  *   "jsplit"         one-sided variants: number of j-chunks a body's sum is split into; variant 7:
  *                    scheduling rounds; variant 8: i-side sub-blocks per item (1, 2, 4, 8, 16).  0 = auto
  *   "taper"          variant 8: percentage (0..100) of each launch's work whose items are cut finer (the last
@@ -292,6 +293,10 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
  *                    of the same device (torch's default stream) synchronises with the force kernels implicitly;
  *                    (ii) it has default priority.  The low-priority stream of "overlap" 2 therefore stays unmasked
  *                    (it keeps its priority and may use the reserved CUs)
+ *   "fuse_integrate" 1 (default): one GPU, one-sided kernel with all j in one chunk (the default up to 6 blocks): the state
+ *                    update runs in the tail of the force launch — one launch per step instead of two, bit-identical results
+ *                    (N = 2 048: 7.2 instead of 13.4 us per step).  0 = two launches, and the round-2 rule for "variant" 0
+ *                    (pair-symmetric from 3 blocks up)
  *   "solo_shard"     r >= 0: in a sharded context only shard r launches force work (timing aid: the
  *                    isolated per-step timeline of one rank of W; results are meaningless).  -1 = off
  *   "force_exchange" 1: run the position exchange even with a single rank/shard (self-test of the

@@ -133,11 +133,11 @@ __device__ __forceinline__ void murb_interact_phi(const murb_f2 xj, const murb_f
 
 // ---- force kernel --------------------------------------------------------------------------------
 // grid.x = i groups of WAVES*R bodies, grid.y = j chunks.  LDS: STAGE layout tiles (8 KiB each).
+// (the body is shared with murb_force_integrate_kernel below; `lds` = the workgroup's STAGE tiles)
 template <int MODE, int R, int WAVES, int STAGE>
-__global__ __launch_bounds__(WAVES * 64) void murb_force_kernel(const MurbForceArgs a)
+__device__ __forceinline__ void murb_force_body(const MurbForceArgs& a, float4* lds)
 {
     static_assert(R % 2 == 0 && MURB_TILE_BODIES % (WAVES * R) == 0, "i groups must tile the layout");
-    __shared__ float4 lds[(MODE == MURB_MODE_PK_DIRECT) ? 1 : STAGE * MURB_TILE_F4];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -238,6 +238,13 @@ __global__ __launch_bounds__(WAVES * 64) void murb_force_kernel(const MurbForceA
         const unsigned long row = (unsigned long)(a.chunk_first + chunk) * a.acc_stride;
         a.accp[row + (unsigned long)(i_slot - a.i_first_slot) + lane] = make_float4(ox, oy, oz, 0.f);
     }
+}
+
+template <int MODE, int R, int WAVES, int STAGE>
+__global__ __launch_bounds__(WAVES * 64) void murb_force_kernel(const MurbForceArgs a)
+{
+    __shared__ float4 lds[(MODE == MURB_MODE_PK_DIRECT) ? 1 : STAGE * MURB_TILE_F4];
+    murb_force_body<MODE, R, WAVES, STAGE>(a, lds);
 }
 
 // ---- balanced persistent schedule -----------------------------------------------------------------
@@ -401,10 +408,10 @@ __device__ __forceinline__ float murb_add_rounded(float v, float a_dt)
     return v + a_dt;
 }
 
-__global__ __launch_bounds__(256) void murb_integrate_kernel(const MurbIntegrateArgs a)
+// One pair of local slots (2 lp, 2 lp + 1): partial sums -> accelerations -> state.
+__device__ __forceinline__ void murb_integrate_pair(const MurbIntegrateArgs& a, const int lp)
 {
 #pragma clang fp contract(off)
-    const int lp = blockIdx.x * blockDim.x + threadIdx.x;   // local pair
     const int s0 = 2 * lp;                                    // local slots s0, s0+1
     if (s0 >= (int)a.acc_stride) return;
 
@@ -487,6 +494,30 @@ __global__ __launch_bounds__(256) void murb_integrate_kernel(const MurbIntegrate
     }
     a.rec_out[ra] = A; a.rec_out[ra + MURB_TILE_PAIRS] = B;
     a.vel[va] = VA; a.vel[va + MURB_TILE_PAIRS] = VB;
+}
+
+__global__ __launch_bounds__(256) void murb_integrate_kernel(const MurbIntegrateArgs a)
+{
+    murb_integrate_pair(a, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// One-sided force launch with the state update in its tail: no second launch.  A step of few bodies on one GPU is two
+// DEPENDENT launches of a few microseconds each, and the gap between them is as long as the kernels (N = 2 048: 13 us per
+// step for 3 us of arithmetic).  Only where ONE workgroup holds an i group's complete sums (one j chunk: gridDim.y = 1, one
+// partial row): it then needs nothing from any other workgroup — a workgroup barrier, and its first threads add the (single)
+// row exactly as murb_integrate_kernel does and move the group's bodies (bit-identical).  It writes the OTHER position buffer,
+// which nobody reads in this launch.  (MEASURED and dropped: the same for several j chunks or ranks, the last of an i group's
+// workgroups — by a ticket counter — doing the update: the device-scope fences this needs on a chip of 8 L2s cost more than
+// the launch they save, N = 2 048 13.3 -> 20.2 us, a rank of 8 at N = 30 000 69 -> 118 us.)
+template <int R, int WAVES, int STAGE>
+__global__ __launch_bounds__(WAVES * 64) void murb_force_integrate_kernel(const MurbForceArgs a, const MurbIntegrateArgs ia)
+{
+    __shared__ float4 lds[STAGE * MURB_TILE_F4];
+    murb_force_body<MURB_MODE_PK_LDS, R, WAVES, STAGE>(a, lds);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();     // the four waves' rows of this i group are written (same CU: visible after the barrier)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (threadIdx.x < WAVES * R / 2) murb_integrate_pair(ia, (int)blockIdx.x * (WAVES * R / 2) + (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------

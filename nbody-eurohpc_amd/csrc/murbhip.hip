@@ -183,7 +183,8 @@ struct murbhip_ctx {
     long sym_pass_mb = 0;     // ... one GPU: budget (MiB) for the partial rows of one pass; 0 = a quarter of the device memory
     int sym_red = -1;         // ... i-side reduction in registers (0) or through LDS (1) (-1 = the plan's default)
     int init_libm_fma = -1;   // murbhip_init_bodies: which build of glibc's sincosf to reproduce (-1 = what this host's libm picks)
-    int energy_sweep = 0;     // murbhip_energy on a pair-symmetric plan: 1 = the separate potential sweep of rounds 1-2 (kept for the A/B)
+    int energy_sweep = 0;
+    int fuse_integrate = 1;   // "fuse_integrate": one-sided plan, the state update in the tail of the step's last force launch     // murbhip_energy on a pair-symmetric plan: 1 = the separate potential sweep of rounds 1-2 (kept for the A/B)
     int exchange_p2p = 0;     // RCCL exchange by grouped ncclSend/ncclRecv instead of ncclReduceScatter / ncclAllGather
     int tri_div = 0;          // ... exchange pipeline: the own-slice triangle's items cut into this many parts more (0 = the plan's choice)
     int pad_aware = 1;        // ... 1: padding slots are not walked (murb_schedule.h, sym_orient); 0: every block as if full (A/B)
@@ -240,6 +241,27 @@ int launch_force(int variant, const MurbForceArgs& a, int i_slots, hipStream_t s
         case kPotentialKernel: return launch_force_t<MURB_MODE_PHI, 8, 4, 4>(a, i_slots, s);
         default: return MURBHIP_E_INVALID;
     }
+}
+// variant 1 with the state update in its tail (murb_force_integrate_kernel).  Few bodies: fewer i bodies per wave, i.e. more
+// and shorter workgroups (N = 2 048 at 8 per wave is 64 workgroups on 256 CUs, each wave walking all j for 8 bodies); the
+// sums of a body do not depend on how many others share its wave, so the results stay those of variant 1, bit for bit.
+template <int R>
+int launch_force_integrate_t(const MurbForceArgs& a, const MurbIntegrateArgs& ia, int i_slots, hipStream_t s)
+{
+    const dim3 grid((unsigned)((i_slots + 4 * R - 1) / (4 * R)), 1, 1);
+    hipLaunchKernelGGL((murb_force_integrate_kernel<R, 4, 4>), grid, dim3(256), 0, s, a, ia);
+    return hip_rc(hipGetLastError());
+}
+int launch_force_integrate(const MurbForceArgs& a, const MurbIntegrateArgs& ia, int i_slots, hipStream_t s)
+{
+    if (const char* lab = std::getenv("MURBHIP_LAB_FUSE_R")) {
+        const int r = std::atoi(lab);
+        return r == 2 ? launch_force_integrate_t<2>(a, ia, i_slots, s) : r == 4 ? launch_force_integrate_t<4>(a, ia, i_slots, s)
+                                                                                : launch_force_integrate_t<8>(a, ia, i_slots, s);
+    }
+    if (i_slots <= 6144) return launch_force_integrate_t<2>(a, ia, i_slots, s);   // tools/rate_curve.py: 2 per wave wins up to 6 000,
+    if (i_slots <= 8192) return launch_force_integrate_t<4>(a, ia, i_slots, s);   // 4 at 7 000 (21.9 vs 22.4 us), all equal from 8 193
+    return launch_force_integrate_t<8>(a, ia, i_slots, s);
 }
 constexpr int kNumVariants = 8;
 constexpr int kOneSidedVariant = 1;     // the persistent schedule (7) measured no faster: DESIGN.md §4.1
@@ -336,6 +358,17 @@ size_t sym_row_bytes(const murbhip_ctx* c, int split)
     return rows * MURB_SYM_BLOCK * 3 * sizeof(float);
 }
 
+// One GPU, few bodies: the one-sided kernel with the state update in its tail (murb_force_integrate_kernel: ONE launch per
+// step, 2 i bodies per wave) against the pair-symmetric plan's two launches (force, row sum + update), by block count —
+// tools/rate_curve.py, us per step, round 3: N = 2 049: 8.9 vs 14.0; 3 000: 9.4 vs 13.9; 3 584: 11.2 vs 14.4; 4 097 (5 blocks):
+// 14.2 vs 14.9, 5 000: 15.0 vs 15.1 (a tie: the pair-symmetric plan stays); 6 000 (6 blocks, where the pair-symmetric items
+// fall badly on the workgroup slots): 16.2 vs 19.8; 7 000: 21.9 vs 20.2; 8 193: 37 vs 27.
+inline bool fused_one_sided_wins(const murbhip_ctx* c)
+{
+    const unsigned long T = c->slots / MURB_SYM_BLOCK;
+    return c->fuse_integrate && c->jsplit == 0 && (T <= 4 || T == 6);
+}
+
 Plan make_plan(const murbhip_ctx* c)
 {
     Plan p{};
@@ -344,7 +377,7 @@ Plan make_plan(const murbhip_ctx* c)
     // (one GPU: rows beyond the budget are handled in passes, so only a rank of several has to fit them whole)
     const auto fits = [&](int split) { return c->world == 1 || c->device_mem == 0 || sym_row_bytes(c, split) < c->device_mem / 2; };
     if (c->variant >= 1 && c->variant <= kNumVariants) p.variant = c->variant;
-    else if (c->world == 1) p.variant = (c->n >= kSymmetricMinBodies && fits(1)) ? kSymmetricVariant : kOneSidedVariant;
+    else if (c->world == 1) p.variant = (c->n >= kSymmetricMinBodies && !fused_one_sided_wins(c) && fits(1)) ? kSymmetricVariant : kOneSidedVariant;
     else p.variant = (sym_items_per_rank(c) >= 400 && fits(1)) ? kSymmetricVariant : kOneSidedVariant;
     p.symmetric = p.variant == kSymmetricVariant;
     if (p.symmetric) {
@@ -409,6 +442,9 @@ Plan make_plan(const murbhip_ctx* c)
     if (c->world == 1) {
         p.parts_local = c->jsplit > 0 ? std::min<int>(c->jsplit, (int)std::min<unsigned long>(tiles_local, kMaxParts))
                                       : auto_parts(c, p.variant, c->slice, tiles_local);
+        // up to 6 blocks the default one-sided launch keeps all j in one chunk: its workgroups then need nothing from each
+        // other and take the state update along (murb_force_integrate_kernel)
+        if (c->jsplit == 0 && c->fuse_integrate && p.variant == kOneSidedVariant && c->slots / MURB_SYM_BLOCK <= 6) p.parts_local = 1;
         p.parts_remote = 0;
     } else {
         // split the requested/auto chunk count between the two launches in proportion to their tiles
@@ -493,7 +529,9 @@ int enqueue_sym_launch(murbhip_ctx* c, Shard& sh, int first, int count, bool own
 inline void note_interactions(murbhip_ctx* c, const Shard& sh, double v) { if (&sh == &c->shards[0]) c->interactions_per_launch = v; }
 
 // Force over the tiles of `which` (0 = own slice / everything when world == 1, 1 = all but own slice).
-int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
+// `then`: the step's state update, to run in the tail of this launch (the one-sided kernel's default variant only;
+// *fused says whether it did — otherwise the caller launches the integrate kernel as usual).
+int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which, const MurbIntegrateArgs* then = nullptr, bool* fused = nullptr)
 {
     MurbForceArgs a{};
     if (!p.symmetric) RC_TRY(ensure_accp(c, sh));
@@ -539,7 +577,12 @@ int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
         int rc = 0;
         const int sp = span_begin(c, sh, kProfForce, sh.compute, &rc);
         RC_TRY(rc);
-        RC_TRY(launch_force(p.variant, a, i_slots, sh.compute));
+        if (then && fused && p.variant == kOneSidedVariant && a.nchunks == 1 && then->nparts == 1) {
+            RC_TRY(launch_force_integrate(a, *then, i_slots, sh.compute));
+            *fused = true;
+        } else {
+            RC_TRY(launch_force(p.variant, a, i_slots, sh.compute));
+        }
         RC_TRY(span_end(sh, sp, sh.compute));
     }
     note_interactions(c, sh, (double)i_slots * (double)a.tiles.count * MURB_TILE_BODIES);
@@ -550,18 +593,13 @@ int enqueue_force(murbhip_ctx* c, Shard& sh, const Plan& p, int which)
 // the second half of the previous step's kick plus the first half of this one's.
 inline float leapfrog_kick(const murbhip_ctx* c, float dt) { return c->lf_half ? 0.5f * (c->lf_last_dt + dt) : 0.5f * dt; }
 
-int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int update_state, const Plan* plan = nullptr,
-                      int scheme = -1, float* acc_out = nullptr, bool acc_from_out = false)
+// What the state update of a step works on (everything but the source of the accelerations, which the launch sites add).
+MurbIntegrateArgs integrate_args(const murbhip_ctx* c, const Shard& sh, int nparts, float dt, int update_state, int scheme = -1,
+                                 float* acc_out = nullptr)
 {
     MurbIntegrateArgs a{};
     a.scheme = scheme >= 0 ? scheme : c->integrator;
     a.kick_dt = leapfrog_kick(c, dt);
-    if (plan && plan->persistent) {
-        a.group_bodies = 32;
-        a.sched[0] = plan->sched[0];
-        a.nsched = 1;
-        if (c->world > 1 && plan->sched[1].nblocks > 0) { a.sched[1] = plan->sched[1]; a.nsched = 2; }
-    }
     a.rec_in = sh.rec[c->cur];
     a.rec_out = sh.rec[c->cur ^ 1];
     a.vel = sh.vel;
@@ -573,6 +611,19 @@ int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int updat
     a.acc_stride = (unsigned int)c->slice;
     a.dt = dt;
     a.update_state = update_state;
+    return a;
+}
+
+int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int update_state, const Plan* plan = nullptr,
+                      int scheme = -1, float* acc_out = nullptr, bool acc_from_out = false)
+{
+    MurbIntegrateArgs a = integrate_args(c, sh, nparts, dt, update_state, scheme, acc_out);
+    if (plan && plan->persistent) {
+        a.group_bodies = 32;
+        a.sched[0] = plan->sched[0];
+        a.nsched = 1;
+        if (c->world > 1 && plan->sched[1].nblocks > 0) { a.sched[1] = plan->sched[1]; a.nsched = 2; }
+    }
     if (acc_from_out) a.acc_planes = sh.acc_out;   // remembered forces: nothing to sum
     if (plan && plan->symmetric && sh.sym_main.passes.size() > 1) {   // several passes: the sums are in the fp64 accumulator
         a.acc64 = sh.sym_acc64;
@@ -582,7 +633,7 @@ int enqueue_integrate(murbhip_ctx* c, Shard& sh, int nparts, float dt, int updat
                            sh.sym_main.part, sh.sym_main.comp_stride, sh.sym_main.rows, a);
         return hip_rc(hipGetLastError());
     }
-    if (!acc_from_out && !a.acc64) RC_TRY(ensure_accp(c, sh));
+    if (!acc_from_out && !a.acc64) { RC_TRY(ensure_accp(c, sh)); a.accp = sh.accp; }
     const unsigned pairs = (unsigned)(c->slice / 2);
     hipLaunchKernelGGL(murb_integrate_kernel, dim3((pairs + 255) / 256), dim3(256), 0, sh.compute, a);
     return hip_rc(hipGetLastError());
@@ -1047,18 +1098,29 @@ int shard_iteration_plain(murbhip_ctx* c, Shard& sh, const Plan& p, float dt, in
     const bool exchange = update_state && (c->world > 1 || c->force_exchange);
     int rc = 0;
     if (!is_idle(c, sh)) rc = [&]() -> int {   // timing aid: see "solo_shard"
+        // one-sided kernel, one GPU, one j chunk: the state update rides in the tail of the force launch (murb_force_integrate_kernel)
+        bool fused = false;
+        MurbIntegrateArgs then{};
+        const bool may_fuse = c->fuse_integrate && !reuse && !p.symmetric && !p.persistent && p.variant == kOneSidedVariant &&
+                              c->world == 1 && p.parts_local + p.parts_remote == 1;
+        if (may_fuse) {
+            RC_TRY(ensure_accp(c, sh));
+            then = integrate_args(c, sh, p.parts_local + p.parts_remote, dt, update_state);
+        }
+        const MurbIntegrateArgs* const tail = may_fuse ? &then : nullptr;
         if (c->world == 1 || reuse) {   // reuse: the forces at these positions are in acc_out, only the update is left
             if (c->gather_pending) HIP_TRY(hipStreamWaitEvent(sh.compute, sh.ev_gathered, 0));
-            if (!reuse) RC_TRY(enqueue_force(c, sh, p, 0));
+            if (!reuse) RC_TRY(enqueue_force(c, sh, p, 0, tail, &fused));
         } else if (c->overlap) {
             RC_TRY(enqueue_force(c, sh, p, 0));   // own slice: written by our own integrate, already ordered
             if (c->gather_pending) RC_TRY(timed_wait(c, sh, kProfWaitGather, sh.compute, sh.ev_gathered));
-            RC_TRY(enqueue_force(c, sh, p, 1));
+            RC_TRY(enqueue_force(c, sh, p, 1, tail, &fused));
         } else {
             if (c->gather_pending) RC_TRY(timed_wait(c, sh, kProfWaitGather, sh.compute, sh.ev_gathered));
             RC_TRY(enqueue_force(c, sh, p, 0));
-            RC_TRY(enqueue_force(c, sh, p, 1));
+            RC_TRY(enqueue_force(c, sh, p, 1, tail, &fused));
         }
+        if (fused) return 0;
         return enqueue_integrate(c, sh, p.parts_local + p.parts_remote, dt, update_state, reuse ? nullptr : &p, -1, nullptr, reuse);
     }();
     if (exchange) rc = shard_exchange(c, sh, c->cur ^ 1, rc);
@@ -1911,6 +1973,7 @@ int murbhip_set_option(murbhip_ctx* c, const char* key, long value)
     else if (k == "xcd_order") c->xcd_order = value ? 1 : 0;
     else if (k == "pad_aware") c->pad_aware = value ? 1 : 0;
     else if (k == "energy_sweep") c->energy_sweep = value ? 1 : 0;
+    else if (k == "fuse_integrate") c->fuse_integrate = value ? 1 : 0;
     else if (k == "exchange_p2p") {
         if (value && (c->exchange != 1 || !rccl().Send || !rccl().Recv)) return MURBHIP_E_STATE;   // needs the RCCL exchange and ncclSend/ncclRecv
         RC_TRY(murbhip_sync(c));

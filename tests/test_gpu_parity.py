@@ -1040,6 +1040,37 @@ def test_energy_from_the_force_evaluation(gpu, O, scheme, n, devices):
         assert abs(p1 - p2) <= 5e-7 * abs(p2) and abs(k1 - k2) <= 1e-12 * abs(k2)
 
 
+@pytest.mark.parametrize("n,devices,opts", [(1, [0], {}), (37, [0], {}), (1000, [0], {}), (2048, [0], {}), (2048, [0], {"integrator": 1}),
+                                            (5000, [0], {"variant": 1}), (5000, [0], {"variant": 1, "jsplit": 5}), (30000, [0], {"variant": 1}),
+                                            (9001, [0, 0], {"variant": 1}), (30000, [0] * 8, {"variant": 1}), (30000, [0] * 4, {"variant": 1, "overlap": 0}),
+                                            (20000, [0, 0, 0], {"variant": 1, "integrator": 1})])
+def test_state_update_in_the_force_launch_changes_nothing(gpu, O, n, devices, opts):
+    """One-sided plan: the state update rides in the tail of the step's last force launch (murb_force_integrate_kernel: the
+    workgroup that draws an i group's last ticket adds the group's partial sums and moves its bodies) instead of a launch
+    of its own ("fuse_integrate" 0).  Same sums in the same order: bit-identical states and accelerations, step after step,
+    one GPU and shards, both integrators, with evaluations and read-outs in between."""
+    s = O.init_bodies(n, "galaxy")
+    kw = {"devices": devices} if len(devices) > 1 else {}
+    with gpu.Simulation(n, soft=SOFT, **kw) as two, gpu.Simulation(n, soft=SOFT, **kw) as one:
+        two.set_option("fuse_integrate", 0)
+        for sim in (two, one):
+            for k, v in opts.items():
+                sim.set_option(k, v)
+            sim.upload(s)
+        for rounds in range(3):
+            for sim in (two, one):
+                sim.steps(DT, 7)
+                sim.compute_acc()            # an evaluation without a state update takes the same route
+            a, b = two.acc(), one.acc()
+            assert all(np.array_equal(bits(x), bits(y)) for x, y in zip(a, b))
+            for sim in (two, one):
+                sim.step(DT)                 # from remembered forces: the plain integrate launch in both
+            a, b = two.state(), one.state()
+            for k in a:
+                assert np.array_equal(bits(a[k]), bits(b[k])), (rounds, k)
+        assert int(one.info("variant")) == 1 and np.isfinite(a["qx"]).all()
+
+
 @pytest.mark.parametrize("n,devices", [(3000, [0]), (30000, [0]), (30000, [0, 0, 0])])
 def test_warmup_changes_nothing(gpu, O, n, devices):
     """murbhip_warmup: untimed force evaluations before a caller's first timed iteration.  The state is untouched, nothing

@@ -15,10 +15,13 @@ DEFAULT = ("500,1000,2048,2049,3000,4097,6000,8193,10000,12289,16000,20481,24000
 ap = argparse.ArgumentParser()
 ap.add_argument("--sizes", default=DEFAULT)
 ap.add_argument("--scheme", default="galaxy")
+ap.add_argument("--opts", default="", help="library options, key=value,key=value")
 args = ap.parse_args()
 PEAK = 256 * 256 * 2.4e9   # flop/s: 256 CUs x 256 fp32 flop per clock x 2.4 GHz
 for n in [int(x) for x in args.sizes.split(",")]:
     with murbhip.Simulation(n, soft=2e8) as sim:
+        for kv in filter(None, args.opts.split(",")):
+            sim.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         sim.init_bodies(args.scheme, 0)
         k = min(1000, max(5, int(0.25 / (n * n / 6e12))))
         sim.steps(3600.0, k); sim.sync()
