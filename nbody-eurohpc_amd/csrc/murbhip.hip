@@ -254,11 +254,6 @@ int launch_force_integrate_t(const MurbForceArgs& a, const MurbIntegrateArgs& ia
 }
 int launch_force_integrate(const MurbForceArgs& a, const MurbIntegrateArgs& ia, int i_slots, hipStream_t s)
 {
-    if (const char* lab = std::getenv("MURBHIP_LAB_FUSE_R")) {
-        const int r = std::atoi(lab);
-        return r == 2 ? launch_force_integrate_t<2>(a, ia, i_slots, s) : r == 4 ? launch_force_integrate_t<4>(a, ia, i_slots, s)
-                                                                                : launch_force_integrate_t<8>(a, ia, i_slots, s);
-    }
     if (i_slots <= 6144) return launch_force_integrate_t<2>(a, ia, i_slots, s);   // tools/rate_curve.py: 2 per wave wins up to 6 000,
     if (i_slots <= 8192) return launch_force_integrate_t<4>(a, ia, i_slots, s);   // 4 at 7 000 (21.9 vs 22.4 us), all equal from 8 193
     return launch_force_integrate_t<8>(a, ia, i_slots, s);
