@@ -95,6 +95,7 @@ struct Shard {
     float* mass = nullptr;       // masses of the local slice as uploaded (metrics)
     float* radius = nullptr;     // radii of the local slice: only after murbhip_init_bodies (the host never sent them)
     double* metrics = nullptr;   // block sums of murb_metrics_kernel, then murbhip_energy's pair potentials (metrics_doubles)
+    double* metrics_host = nullptr;   // its pinned host copy: the read-out is one asynchronous copy behind the kernels
     // pair-symmetric kernel: item table and partial-row layouts (built by build_sym_schedule for one plan)
     MurbSymItem* sym_items = nullptr;
     int sym_items_own = 0, sym_items_total = 0;   // [0, own) = own-slice triangle, the rest need the gathered positions
@@ -1462,6 +1463,7 @@ int murbhip_destroy(murbhip_ctx* c)
         for (hipEvent_t* e : {&sh.ev_tri, &sh.ev_integrated, &sh.ev_gathered, &sh.ev_rowsum, &sh.ev_reduced}) release_event(*e);
         for (hipStream_t* q : {&sh.compute_low, &sh.compute, &sh.comm}) release_stream(*q);
         release(sh.rec[0], sh.rec[1], sh.vel, sh.accp, sh.acc_out, sh.phi_out, sh.mass, sh.radius, sh.metrics);
+        if (sh.metrics_host) (void)hipHostFree(sh.metrics_host);
         release(sh.sym_items, sh.sym_send, sh.sym_recv, sh.sym_p2p, sh.sym_tri_acc, sh.sym_acc64);
         free_sym_set(sh.sym_main); free_sym_set(sh.sym_tri);
     }
@@ -1813,14 +1815,15 @@ int device_metrics(murbhip_ctx* c, bool want_phi, double (&sums)[MURB_METRIC_VAL
         a.g_over_soft = (double)c->g / std::sqrt((double)c->soft2);
         hipLaunchKernelGGL(murb_metrics_kernel, dim3((unsigned)l.blocks), dim3(256), 0, sh.compute, a);
         RC_TRY(hip_rc(hipGetLastError()));
+        // the read-out rides behind the kernels on the same stream, into pinned memory: one wait for everything
+        if (!sh.metrics_host) HIP_TRY(hipHostMalloc((void**)&sh.metrics_host, l.total * sizeof(double), hipHostMallocDefault));
+        HIP_TRY(hipMemcpyAsync(sh.metrics_host, sh.metrics, (pair_sum ? l.total : l.pe_main) * sizeof(double), hipMemcpyDeviceToHost, sh.compute));
     }
     RC_TRY(murbhip_sync(c));
     for (double& v : sums) v = 0.0;
     if (pair_sum) *pair_sum = 0.0;
-    std::vector<double> host(pair_sum ? l.total : l.pe_main);
     for (Shard& sh : c->shards) {
-        HIP_TRY(hipSetDevice(sh.device));
-        HIP_TRY(hipMemcpy(host.data(), sh.metrics, host.size() * sizeof(double), hipMemcpyDeviceToHost));
+        const double* const host = sh.metrics_host;
         for (size_t b = 0; b < l.blocks; ++b)
             for (int k = 0; k < MURB_METRIC_VALUES; ++k) sums[k] += host[b * MURB_METRIC_VALUES + k];
         if (!pair_sum) continue;
