@@ -246,15 +246,18 @@ int launch_force(int variant, const MurbForceArgs& a, int i_slots, hipStream_t s
 // variant 1 with the state update in its tail (murb_force_integrate_kernel).  Few bodies: fewer i bodies per wave, i.e. more
 // and shorter workgroups (N = 2 048 at 8 per wave is 64 workgroups on 256 CUs, each wave walking all j for 8 bodies); the
 // sums of a body do not depend on how many others share its wave, so the results stay those of variant 1, bit for bit.
-template <int R>
+template <int R, int WAVES = 4>
 int launch_force_integrate_t(const MurbForceArgs& a, const MurbIntegrateArgs& ia, int i_slots, hipStream_t s)
 {
-    const dim3 grid((unsigned)((i_slots + 4 * R - 1) / (4 * R)), 1, 1);
-    hipLaunchKernelGGL((murb_force_integrate_kernel<R, 4, 4>), grid, dim3(256), 0, s, a, ia);
+    const dim3 grid((unsigned)((i_slots + WAVES * R - 1) / (WAVES * R)), 1, 1);
+    hipLaunchKernelGGL((murb_force_integrate_kernel<R, WAVES, 4>), grid, dim3(64 * WAVES), 0, s, a, ia);
     return hip_rc(hipGetLastError());
 }
 int launch_force_integrate(const MurbForceArgs& a, const MurbIntegrateArgs& ia, int i_slots, hipStream_t s)
 {
+    // 8 waves share a workgroup's staged j tiles up to 4 blocks (N = 2 048: 6.9 vs 7.3 us per step, 3 000: 8.6 vs 9.4,
+    // 4 096: 10.2 vs 11.4; 5 000: 15.5 vs 14.9, 6 000: 18.2 vs 16.2 — profiles/r03_fused_small_steps.txt)
+    if (i_slots <= 4096) return launch_force_integrate_t<2, 8>(a, ia, i_slots, s);
     if (i_slots <= 6144) return launch_force_integrate_t<2>(a, ia, i_slots, s);   // tools/rate_curve.py: 2 per wave wins up to 6 000,
     if (i_slots <= 8192) return launch_force_integrate_t<4>(a, ia, i_slots, s);   // 4 at 7 000 (21.9 vs 22.4 us), all equal from 8 193
     return launch_force_integrate_t<8>(a, ia, i_slots, s);
