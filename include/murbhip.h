@@ -229,8 +229,8 @@ int murbhip_moments(murbhip_ctx* ctx, double* out10);
 /* Integer options.  Keys:
  *   "variant"        force kernel variant.  0 = auto: the pair-symmetric kernel (8) on one
  *                    GPU from 4 097 bodies (5 blocks of 1024) up, except at 6 blocks, and in multi-GPU runs when a rank gets
- *                    >= 400 block pairs, the one-sided kernel (1) otherwise (one GPU: with the state update in the tail of
- *                    its launch, see "fuse_integrate").  1-6: one-sided variants, 7: persistent schedule
+ *                    >= 400 block pairs, the one-sided kernel otherwise (1; 2 = four i bodies per wave for a rank's slice of up
+ *                    to 16 384 bodies; one GPU: with the state update in the tail of its launch, see "fuse_integrate").  1-6: one-sided variants, 7: persistent schedule
  *   "jsplit"         one-sided variants: number of j-chunks a body's sum is split into; variant 7:
  *                    scheduling rounds; variant 8: i-side sub-blocks per item (1, 2, 4, 8, 16).  0 = auto
  *   "taper"          variant 8: percentage (0..100) of each launch's work whose items are cut finer (the last

@@ -264,6 +264,9 @@ int launch_force_integrate(const MurbForceArgs& a, const MurbIntegrateArgs& ia, 
 }
 constexpr int kNumVariants = 8;
 constexpr int kOneSidedVariant = 1;     // the persistent schedule (7) measured no faster: DESIGN.md §4.1
+constexpr int kOneSidedFewBodies = 2;   // 4 i bodies per wave instead of 8: twice the workgroups for a rank's small slice (tools/solo_rank.py,
+                                        // round 3, one rank alone: N = 30 000 W = 2/4/8 148 -> 138, 92 -> 86, 69 -> 63 us per step; N = 16 000
+                                        // W = 4: 54 -> 43; N = 45 000 W = 8: 108 -> 99; equal from ~20 000 bodies per rank)
 constexpr int kPersistentVariant = 7;   // murb_force_persistent<8, 4, 4>
 constexpr int kSymmetricVariant = 8;    // murb_force_sym_kernel<4, 4 or 8>
 constexpr unsigned long kSymmetricMinBodies = 2049;    // below this (one or two blocks) the one-sided kernel wins; round 2: 10 240 —
@@ -377,7 +380,7 @@ Plan make_plan(const murbhip_ctx* c)
     const auto fits = [&](int split) { return c->world == 1 || c->device_mem == 0 || sym_row_bytes(c, split) < c->device_mem / 2; };
     if (c->variant >= 1 && c->variant <= kNumVariants) p.variant = c->variant;
     else if (c->world == 1) p.variant = (c->n >= kSymmetricMinBodies && !fused_one_sided_wins(c) && fits(1)) ? kSymmetricVariant : kOneSidedVariant;
-    else p.variant = (sym_items_per_rank(c) >= 400 && fits(1)) ? kSymmetricVariant : kOneSidedVariant;
+    else p.variant = (sym_items_per_rank(c) >= 400 && fits(1)) ? kSymmetricVariant : (c->slice <= 16384 ? kOneSidedFewBodies : kOneSidedVariant);
     p.symmetric = p.variant == kSymmetricVariant;
     if (p.symmetric) {
         // finer items (i side cut in 2 or 4) until a GPU has ~8 scheduling rounds of them; ~16 in the
