@@ -239,7 +239,8 @@ int launch_force(int variant, const MurbForceArgs& a, int i_slots, hipStream_t s
         case 4: return launch_force_t<MURB_MODE_SC_LDS, 8, 4, 4>(a, i_slots, s);
         case 5: return launch_force_t<MURB_MODE_PK_LDS, 16, 4, 4>(a, i_slots, s);
         case 6: return launch_force_t<MURB_MODE_PK_DIRECT, 4, 4, 1>(a, i_slots, s);
-        case kPotentialKernel: return launch_force_t<MURB_MODE_PHI, 8, 4, 4>(a, i_slots, s);
+        case kPotentialKernel:   // few bodies: 2 per wave and 8 waves per workgroup, like murb_force_integrate_kernel (same sums per body)
+            return i_slots <= 8192 ? launch_force_t<MURB_MODE_PHI, 2, 8, 4>(a, i_slots, s) : launch_force_t<MURB_MODE_PHI, 8, 4, 4>(a, i_slots, s);
         default: return MURBHIP_E_INVALID;
     }
 }
